@@ -1,0 +1,80 @@
+/* TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, fp64) of the jinkakei/q-gcm ocean hot path
+ *   qgostep -> ocinvq -> ocqbdy   (src/q-gcm.F:1243-1249)
+ * plus the init-time routines that feed it (eigmod, homsol, constr, qcomp,
+ * merqcy).  It is the checker for the HIP path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it.
+ * Every function cites the reference lines it follows.
+ *
+ * Pinning: validated against the true reference compiled from
+ * /root/reference/src (oracle/build_ref.sh -> oracle/_ref/) and against the
+ * golden vectors under tests/golden/ that were generated from that build
+ * (tests/golden/make_golden.py).  See tests/test_oracle_vs_golden.py.
+ *
+ * Arrays are Fortran ordered: element (i,j,k), 1-based, lives at
+ * (i-1) + nxpo*((j-1) + nypo*(k-1)).
+ */
+#ifndef QGCM_ORACLE_H
+#define QGCM_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qgo_ctx qgo_ctx;
+
+/* grid + physical parameters (src/parameters_data.F, src/in_param.f) */
+qgo_ctx *qgo_create(int nxpo, int nypo, int nlo, int cyclic,
+                    double fnot, double beta, double dxo, double dto,
+                    double delek, double bccooc,
+                    const double *ah2oc, const double *ah4oc,
+                    const double *hoc, const double *gpoc,
+                    const double *yporel, const double *ddynoc);
+void qgo_destroy(qgo_ctx *c);
+void qgo_set_threads(int nthreads);
+
+/* state */
+void qgo_set_p(qgo_ctx *c, const double *po, const double *pom); /* + constr, qcomp, ocqbdy, merqcy */
+void qgo_set_state(qgo_ctx *c, const double *po, const double *pom, const double *qo, const double *qom);
+void qgo_get_state(qgo_ctx *c, double *po, double *pom, double *qo, double *qom);
+void qgo_set_forcing(qgo_ctx *c, const double *wekpo, const double *entoc, const double *xon);
+void qgo_set_cyc_forcing(qgo_ctx *c, double txis, double txin, const double *enis, const double *enin);
+/* scal = dpioc(nlo-1), dpiocp(nlo-1), ocncs, ocncn, ocncsp, ocncnp (nlo each; zero for box) */
+void qgo_get_scalars(qgo_ctx *c, double *scal);
+void qgo_set_scalars(qgo_ctx *c, const double *scal);
+/* diagnostics of the last ocinvq: xinhom(nlo), then hclco(nlo-1) [box] or c1(nlo-1),c2(nlo-1),c3 [cyclic] */
+void qgo_get_inv_diag(qgo_ctx *c, double *xinhom, double *coef);
+
+/* constants */
+void qgo_get_consts(qgo_ctx *c, double *amatoc, double *ctl2moc, double *ctm2loc,
+                    double *rdm2oc, double *bd2oc, double *aoc);
+/* box: hom = ochom(nxpo,nypo,nlo-1), aux = aipohs, cdiffo(nlo,nlo-1), cdhoc(nlo-1,nlo-1)
+ * cyc: hom = pch1oc(nypo,nlo-1), pch2oc(nypo,nlo-1), pbhoc(nypo);
+ *      aux = aipcho, hc1soc, hc2soc, hc1noc, hc2noc (nlo-1 each), hbsioc, aipbho */
+void qgo_get_homog(qgo_ctx *c, double *hom, double *aux);
+
+/* the path */
+void qgo_qgostep(qgo_ctx *c);
+void qgo_ocinvq(qgo_ctx *c);
+void qgo_ocqbdy(qgo_ctx *c);
+void qgo_lf_average(qgo_ctx *c);
+void qgo_steps(qgo_ctx *c, int s0, int n);
+
+/* building blocks */
+void qgo_project(qgo_ctx *c, double *wrk);                 /* ocisubs.F:117-139 */
+void qgo_helmholtz(qgo_ctx *c, double *wrk, const double *boc); /* hsbxoc / hscyoc */
+double qgo_xintp(const double *val, int nx, int ny);        /* intsubs.f:78-133 */
+void qgo_dsint(int n, double *x);                           /* x has n+1 elements */
+void qgo_rfftf(int n, double *x);                           /* FFTPACK half-complex layout */
+void qgo_rfftb(int n, double *x);
+void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
+                double *amat, double *rdm2, double *ctl2m, double *ctm2l);
+/* ocean-only Ekman pumping from wind stress, xfosubs.F:138,566-645 */
+void qgo_wekpo_from_tau(int nxpo, int nypo, int cyclic, double dxo, double fnot,
+                        const double *tauxo, const double *tauyo, double *wekto, double *wekpo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,227 @@
+"""TEST INFRASTRUCTURE ONLY (oracle) - ctypes view of oracle/_ref/libqgcm_ref_<cfg>.so.
+
+The library is the *true reference* (jinkakei/q-gcm Fortran + FFTPACK) compiled
+by oracle/build_ref.sh plus our harness oracle/ref/qgcm_ref_harness.F90.  It is
+used (a) in this container to generate tests/golden/ and to validate the C
+restatement oracle/qgcm_oracle.c, and (b) by bench.py's ``cpu_baseline`` leg
+(kind "reference").  Nothing in the product path may import this module.
+
+All arrays are Fortran ordered float64, shapes (nxpo, nypo, nlo) etc.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(HERE, "_ref")
+
+# name -> (nxta, nyta, nxaooc, nyaooc, ndxr, nlo, fnot, beta, cyclic)
+# box_natl5 / cyc_socn5 are exactly examples/double_gyre_ocean_only/parameters_data.F.dg_oo
+# and examples/southern_ocean_ocean_only/parameters_data.F.so_oo.
+CONFIGS = {
+    "box_tiny": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0),
+    "box_small": (12, 10, 6, 5, 16, 3, "9.37456D-05", "1.75360D-11", 0),
+    "box_tiny2": (8, 8, 5, 4, 6, 2, "5.92D-05", "2.08D-11", 0),
+    "cyc_tiny": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1),
+    "cyc_small": (6, 10, "nxta", 4, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
+    "box_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0),
+    "cyc_socn5": (288, 108, "nxta", 36, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
+}
+
+
+def lib_path(cfg):
+    return os.path.join(REFDIR, "libqgcm_ref_%s.so" % cfg)
+
+
+def build(cfg, force=False):
+    """Compile the reference for one config (no-op when /root/reference is absent)."""
+    import subprocess
+    if os.path.exists(lib_path(cfg)) and not force:
+        return lib_path(cfg)
+    p = CONFIGS[cfg]
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), cfg] + [str(x) for x in p])
+    return lib_path(cfg)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def run_big_stack(fn, *args):
+    """The reference keeps 22 MB automatic arrays (src/qgosubs.F:64-66): call it on
+    a thread with a large stack instead of requiring ``ulimit -s unlimited``."""
+    out = {}
+
+    def tgt():
+        try:
+            out["r"] = fn(*args)
+        except BaseException as e:  # pragma: no cover
+            out["e"] = e
+    old = threading.stack_size(1 << 30)
+    try:
+        t = threading.Thread(target=tgt)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(old)
+    if "e" in out:
+        raise out["e"]
+    return out.get("r")
+
+
+class RefLib:
+    def __init__(self, cfg):
+        os.environ.setdefault("OMP_STACKSIZE", "1G")
+        path = lib_path(cfg)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.cfg = cfg
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)  # MKL dlopens its kernels against libmkl_core symbols
+        nx, ny, nl, cyc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.ref_dims(C.byref(nx), C.byref(ny), C.byref(nl), C.byref(cyc))
+        self.nx, self.ny, self.nl, self.cyclic = nx.value, ny.value, nl.value, cyc.value
+        f0, b = C.c_double(), C.c_double()
+        self.lib.ref_params(C.byref(f0), C.byref(b))
+        self.fnot, self.beta = f0.value, b.value
+        self.nscal = 2 * (self.nl - 1) + 4 * self.nl
+
+    # -- helpers -------------------------------------------------------
+    def _f3(self):
+        return np.zeros((self.nx, self.ny, self.nl), order="F")
+
+    def _f2(self):
+        return np.zeros((self.nx, self.ny), order="F")
+
+    def init(self, dxo, dto, delek, bccooc, ah2oc, ah4oc, hoc, gpoc, ddynoc=None):
+        ah2 = np.ascontiguousarray(ah2oc, dtype=np.float64)
+        ah4 = np.ascontiguousarray(ah4oc, dtype=np.float64)
+        h = np.ascontiguousarray(hoc, dtype=np.float64)
+        g = np.ascontiguousarray(gpoc, dtype=np.float64)
+        dd = self._f2() if ddynoc is None else np.asfortranarray(ddynoc, dtype=np.float64)
+        self.lib.ref_init.argtypes = [C.c_double] * 4 + [C.POINTER(C.c_double)] * 5
+        run_big_stack(self.lib.ref_init, dxo, dto, delek, bccooc, _dp(ah2), _dp(ah4), _dp(h), _dp(g), _dp(dd))
+
+    def set_p(self, po, pom):
+        po = np.asfortranarray(po, dtype=np.float64)
+        pom = np.asfortranarray(pom, dtype=np.float64)
+        run_big_stack(self.lib.ref_set_p, _dp(po), _dp(pom))
+
+    def set_state(self, po, pom, qo, qom):
+        a = [np.asfortranarray(x, dtype=np.float64) for x in (po, pom, qo, qom)]
+        self.lib.ref_set_state(*[_dp(x) for x in a])
+
+    def get_state(self):
+        a = [self._f3() for _ in range(4)]
+        self.lib.ref_get_state(*[_dp(x) for x in a])
+        return a
+
+    def set_forcing(self, wekpo, entoc=None, xon=None):
+        w = np.asfortranarray(wekpo, dtype=np.float64)
+        e = self._f2() if entoc is None else np.asfortranarray(entoc, dtype=np.float64)
+        x = np.zeros(self.nl - 1) if xon is None else np.ascontiguousarray(xon, dtype=np.float64)
+        self.lib.ref_set_forcing(_dp(w), _dp(e), _dp(x))
+
+    def set_cyc_forcing(self, txis, txin, enis=None, enin=None):
+        es = np.zeros(self.nl - 1) if enis is None else np.ascontiguousarray(enis, dtype=np.float64)
+        en = np.zeros(self.nl - 1) if enin is None else np.ascontiguousarray(enin, dtype=np.float64)
+        self.lib.ref_set_cyc_forcing.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        self.lib.ref_set_cyc_forcing(txis, txin, _dp(es), _dp(en))
+
+    def get_scalars(self):
+        s = np.zeros(self.nscal)
+        self.lib.ref_get_scalars(_dp(s))
+        return s
+
+    def set_scalars(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        self.lib.ref_set_scalars(_dp(s))
+
+    def get_consts(self):
+        nl = self.nl
+        amat = np.zeros((nl, nl), order="F")
+        cl2m = np.zeros((nl, nl), order="F")
+        cm2l = np.zeros((nl, nl), order="F")
+        rdm2 = np.zeros(nl)
+        bd2 = np.zeros(self.nx - 1)
+        ypr = np.zeros(self.ny)
+        aoc = C.c_double()
+        self.lib.ref_get_consts(_dp(amat), _dp(cl2m), _dp(cm2l), _dp(rdm2), _dp(bd2), _dp(ypr), C.byref(aoc))
+        return dict(amatoc=amat, ctl2moc=cl2m, ctm2loc=cm2l, rdm2oc=rdm2, bd2oc=bd2, yporel=ypr, aoc=aoc.value)
+
+    def get_homog(self):
+        nl, nx, ny = self.nl, self.nx, self.ny
+        if self.cyclic:
+            hom = np.zeros(ny * (2 * (nl - 1) + 1))
+            aux = np.zeros(5 * (nl - 1) + 2)
+            self.lib.ref_get_homog(_dp(hom), _dp(aux))
+            n1 = ny * (nl - 1)
+            return dict(pch1oc=hom[:n1].reshape((ny, nl - 1), order="F").copy(order="F"),
+                        pch2oc=hom[n1:2 * n1].reshape((ny, nl - 1), order="F").copy(order="F"),
+                        pbhoc=hom[2 * n1:].copy(),
+                        aipcho=aux[0:nl - 1].copy(), hc1soc=aux[nl - 1:2 * (nl - 1)].copy(),
+                        hc2soc=aux[2 * (nl - 1):3 * (nl - 1)].copy(), hc1noc=aux[3 * (nl - 1):4 * (nl - 1)].copy(),
+                        hc2noc=aux[4 * (nl - 1):5 * (nl - 1)].copy(), hbsioc=aux[5 * (nl - 1)], aipbho=aux[5 * (nl - 1) + 1])
+        hom = np.zeros(nx * ny * (nl - 1))
+        aux = np.zeros((nl - 1) + nl * (nl - 1) + (nl - 1) ** 2)
+        self.lib.ref_get_homog(_dp(hom), _dp(aux))
+        o = nl - 1
+        return dict(ochom=hom.reshape((nx, ny, nl - 1), order="F").copy(order="F"),
+                    aipohs=aux[:o].copy(),
+                    cdiffo=aux[o:o + nl * (nl - 1)].reshape((nl, nl - 1), order="F").copy(order="F"),
+                    cdhoc=aux[o + nl * (nl - 1):].reshape((nl - 1, nl - 1), order="F").copy(order="F"))
+
+    def qgostep(self):
+        run_big_stack(self.lib.ref_qgostep)
+
+    def ocinvq(self):
+        run_big_stack(self.lib.ref_ocinvq)
+
+    def ocqbdy(self):
+        run_big_stack(self.lib.ref_ocqbdy)
+
+    def lf_average(self):
+        self.lib.ref_lf_average()
+
+    def steps(self, s0, n):
+        self.lib.ref_steps.argtypes = [C.c_int, C.c_int]
+        run_big_stack(self.lib.ref_steps, int(s0), int(n))
+
+    def helmholtz(self, wrk, boc):
+        w = np.asfortranarray(wrk, dtype=np.float64).copy(order="F")
+        b = np.ascontiguousarray(boc, dtype=np.float64)
+        run_big_stack(self.lib.ref_helmholtz, _dp(w), _dp(b))
+        return w
+
+    def xintp(self, val):
+        v = np.asfortranarray(val, dtype=np.float64)
+        r = C.c_double()
+        self.lib.ref_xintp(_dp(v), C.byref(r))
+        return r.value
+
+    def dsint(self, x):
+        n = len(x)
+        buf = np.zeros(n + 1)
+        buf[:n] = x
+        self.lib.ref_dsint.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        self.lib.ref_dsint(n, _dp(buf))
+        return buf[:n].copy()
+
+    def drfft(self, x, dirn=+1):
+        buf = np.array(x, dtype=np.float64)
+        self.lib.ref_drfft.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int]
+        self.lib.ref_drfft(len(buf), _dp(buf), dirn)
+        return buf
+
+    def eigmod(self, gpr, h):
+        nl = len(h)
+        g = np.ascontiguousarray(gpr, dtype=np.float64)
+        hh = np.ascontiguousarray(h, dtype=np.float64)
+        amat = np.zeros((nl, nl), order="F")
+        cl2m = np.zeros((nl, nl), order="F")
+        cm2l = np.zeros((nl, nl), order="F")
+        rdm2 = np.zeros(nl)
+        self.lib.ref_eigmod.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
+        self.lib.ref_eigmod(nl, _dp(g), _dp(hh), _dp(amat), _dp(rdm2), _dp(cl2m), _dp(cm2l))
+        return dict(amatoc=amat, rdm2oc=rdm2, ctl2moc=cl2m, ctm2loc=cm2l)
