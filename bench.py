@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py - ocean timesteps/s of the MI355X-native Q-GCM PV-advance/inversion path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one ocean timestep of the hot path: qgostep -> ocinvq -> ocqbdy (+ the
+leapfrog averaging every 25th step), src/q-gcm.F:1243-1249,1328-1366, on the
+synthetic NAtl-5km-shaped 3-layer grid (961 x 961 x 3, fp64; BASELINE.json
+configs[1]) with all inputs resident in HBM.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel: algorithmic bytes per launch / HIP-event average
+                launch duration measured live on the library's stream, against the
+                nominal 8 TB/s HBM peak (MI355X_MICROARCH.md).
+  cpu_baseline  the true reference Fortran+FFTPACK path (oracle/_ref, kind
+                "reference") or, if that library is absent, the C restatement
+                (kind "port"), timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "q-gcm_amd", "python"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # nominal MI355X HBM3E peak (MI355X_MICROARCH.md)
+WORKLOAD = "natl5"
+
+# Algorithmic bytes per launch in units of N*8 B (N = nxpo*nypo), SURVEY.md 8(d):
+# P1 tendency+leapfrog+projection 24, P2/P4 row transforms 6 each, P3 Thomas 6,
+# P5 unpack 14 (box).  "own" = what this implementation's kernel has to move
+# (rotating time-level buffers: no qom/pom rewrite, no po re-read) - DESIGN.md.
+ALGO_FIELDS = {"k_tend": (24, 21), "k_dst_fwd": (6, 6), "k_thomas": (6, 6), "k_dst_inv": (6, 6),
+               "k_unpack": (14, 8), "k_constr": (0, 0), "k_ocqbdy": (0, 0), "k_lf_average": (0, 0)}
+
+
+@contextlib.contextmanager
+def quiet_stdout():
+    """The reference Fortran prints its start-up report on fd 1; keep our one JSON line clean."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+
+
+def synthetic_inputs(cfg):
+    from qgcm_hip import synth
+    po = synth.gaussian_eddy(cfg)              # IC B of SURVEY 8d
+    tx, ty = synth.wind_stress(cfg)            # double-gyre wind
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    return po, wek
+
+
+def cpu_baseline(cfg, po, wek, budget_s=15.0):
+    """Reference (or port) ocean steps/s on the host cores; bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    cores = len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_STACKSIZE", "1G")
+    zeros2 = np.zeros_like(wek)
+    kind, model = None, None
+    try:
+        import ref_binding
+        if os.path.exists(ref_binding.lib_path("box_natl5")):
+            with quiet_stdout():
+                r = ref_binding.RefLib("box_natl5")
+                assert (r.nx, r.ny, r.nl) == (cfg.nxpo, cfg.nypo, cfg.nlo)
+                r.init(cfg.dxo, cfg.dto, cfg.delek, cfg.bccooc, cfg.ah2oc, cfg.ah4oc, cfg.hoc, cfg.gpoc)
+                r.set_p(po, po)
+                r.set_forcing(wek, zeros2, np.zeros(cfg.nlo - 1))
+            kind, model = "reference", r
+    except Exception as e:  # fall back to the port, say why
+        print("cpu_baseline: reference library unusable (%s); timing the C port" % e, file=sys.stderr)
+    if model is None:
+        import oracle_binding as ob
+        ob.set_threads(cores)
+        o = ob.Oracle(cfg.nxpo, cfg.nypo, cfg.nlo, cfg.cyclic, cfg.fnot, cfg.beta, cfg.dxo, cfg.dto, cfg.delek,
+                      cfg.bccooc, cfg.ah2oc, cfg.ah4oc, cfg.hoc, cfg.gpoc, cfg.yporel())
+        o.set_p(po, po)
+        o.set_forcing(wek, zeros2, np.zeros(cfg.nlo - 1))
+        kind, model = "port", o
+    with quiet_stdout():
+        model.steps(1, 5)  # warm-up
+        t0 = time.perf_counter()
+        model.steps(6, 10)
+        per = (time.perf_counter() - t0) / 10
+        n = int(max(10, min(2000, budget_s / per)))
+        t0 = time.perf_counter()
+        model.steps(16, n)
+        dt = time.perf_counter() - t0
+    sps = n / dt
+    return {"value": round(sps, 3), "unit": "steps/s", "cores": cores, "kind": kind,
+            "ms_per_step": round(1e3 / sps, 4), "model_years_per_day": round(cfg.model_years_per_day(sps), 2),
+            "sample": "%d ocean steps of the same %s workload (Gaussian-eddy IC, double-gyre wind), "
+                      "%d OpenMP threads, %.1f s" % (n, WORKLOAD, cores, dt)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary, if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path)).get(kernel)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1600)
+    ap.add_argument("--warmup", type=int, default=160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)"
+                             % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from qgcm_hip import OceanModel, preset
+    cfg = preset(WORKLOAD)
+    po, wek = synthetic_inputs(cfg)
+    model = OceanModel(cfg, device=local_rank)
+    model.set_p(po, po)
+    model.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    model.steps(args.warmup, s0=1)
+    barrier()
+    t0 = time.perf_counter()
+    ev_ms = model.time_steps(args.steps, s0=args.warmup + 1)  # HIP events on the library's stream
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    state = model.get_state()
+    finite = bool(all(np.isfinite(x).all() for x in state))
+
+    # ---- per-kernel HIP-event timing for the roofline entry (rank 0) ---------
+    out = None
+    if rank == 0:
+        nprof = 100
+        prof = model.profile_steps(nprof, s0=args.warmup + args.steps + 1)
+        npts = cfg.nxpo * cfg.nypo
+        dom = max(prof, key=lambda k: prof[k][0])
+        tot_ms, nl = prof[dom]
+        avg_us = 1e3 * tot_ms / max(nl, 1)
+        f_survey, f_own = ALGO_FIELDS[dom]
+        abytes = f_survey * npts * 8.0
+        achieved = abytes / (avg_us * 1e-6) / 1e9
+        copy_gbs = model.copy_bandwidth(1 << 30, 10)
+        steps_per_s = world * args.steps / wall
+        out = {
+            "metric": "ocean timesteps/sec (NAtl 5km 3-layer qgostep+ocinvq+ocqbdy)",
+            "value": round(steps_per_s, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "double_gyre_ocean_only NAtl 5km, 961x961x3 p-grid, dto=540s, "
+                                   "Gaussian-eddy IC + double-gyre wind, oml off",
+                       "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
+                       "parallelism": "single GPU" if world == 1 else "%d independent ensemble members (no domain decomposition yet)" % world},
+            "model_years_per_day": round(cfg.model_years_per_day(steps_per_s), 1),
+            "hip_event_ms_per_step": round(ev_ms / args.steps, 5),
+            "state_finite": finite,
+            "step_hbm_frac": round(56 * npts * 8.0 * (args.steps / (ev_ms * 1e-3)) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
+                         "avg_launch_us": round(avg_us, 3), "algorithmic_bytes_per_launch": abytes,
+                         "frac_own_traffic": round(f_own * npts * 8.0 / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "measured_copy_GBps": round(copy_gbs, 1),
+                         "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 3) for k, v in prof.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            model.close()
+            out["cpu_baseline"] = cpu_baseline(cfg, po, wek)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

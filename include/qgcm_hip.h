@@ -1,0 +1,147 @@
+/* qgcm_hip.h - C ABI of the MI355X-native Q-GCM ocean PV-advance / inversion path.
+ *
+ * Drop-in boundary for the three argument-less calls the reference main
+ * program makes once per ocean step (src/q-gcm.F:1243-1249):
+ *
+ *     call qgostep          -> qgcm_hip_qgostep()   (src/qgosubs.F:45-221 + ocadif 231-446)
+ *     call ocinvq           -> qgcm_hip_ocinvq()    (src/ocisubs.F:64-407, hsbxoc 415-512, hscyoc 521-618)
+ *     call ocqbdy (qo, po)  -> qgcm_hip_ocqbdy()    (src/vorsubs.F:245-388)
+ *
+ * plus the leapfrog time-level averaging block (src/q-gcm.F:1328-1366), the
+ * Helmholtz solver that homsol calls at start-up (src/conhoms.F:454-455,572)
+ * and the data movement that replaces the reference's shared module arrays
+ * (ocstate: src/ocstate_data.F:39-42; occonst: src/occonst_data.F:36-44;
+ * ochomog: src/ochomog_data.F:44-68; ocisubs: src/ocisubs.F:51-55).
+ *
+ * Conventions
+ *  - plain C: raw double pointers + sizes, no Fortran descriptors, no torch types.
+ *  - every host array is Fortran ordered exactly as the reference declares
+ *    it, e.g. po(nxpo,nypo,nlo): element (i,j,k) 1-based at
+ *    (i-1) + nxpo*((j-1) + nypo*(k-1)).  Host buffers are caller-owned and
+ *    never retained.
+ *  - the device owns the authoritative po,pom,qo,qom between set_state and
+ *    get_state; all kernels run on one HIP stream owned by the handle.
+ *  - every entry point returns 0 on success, non-zero on failure;
+ *    qgcm_hip_last_error() returns a static description.  The reference's
+ *    own convention is print + stop (e.g. src/ocisubs.F:361-365); the Fortran
+ *    shim (q-gcm_amd/fortran) restores that behaviour.
+ *  - one host thread per handle (the reference is called from its single
+ *    main thread); calls are asynchronous until qgcm_hip_sync / a get_*.
+ *  - there is NO CPU fallback: without a HIP device create() fails.
+ */
+#ifndef QGCM_HIP_H
+#define QGCM_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QGCM_HIP_MAXL 8 /* max number of QG layers supported (nlo <= 8) */
+#define QGCM_HIP_ABI_VERSION 1
+
+typedef struct qgcm_hip_ctx *qgcm_hip_handle;
+
+/* Scalars + small matrices of MODULE parameters / occonst / ochomog that the
+ * path reads (src/parameters_data.F:23-147, src/occonst_data.F:36-44).
+ * Matrices are Fortran ordered with leading dimension nlo, packed. */
+typedef struct qgcm_hip_params {
+  int nxpo, nypo, nlo; /* p-grid size, layers */
+  int cyclic;          /* 1 = -Dcyclic_ocean (hscyoc path), 0 = box (hsbxoc) */
+  double fnot, beta;   /* parameters_data.F: fnot, beta */
+  double dxo, dyo;     /* occonst: grid spacing (dyo = dxo in the reference) */
+  double tdto;         /* occonst: 2*dto */
+  double delek;        /* bottom Ekman layer thickness */
+  double bccooc;       /* mixed BC coefficient */
+  double ah2oc[QGCM_HIP_MAXL];
+  double ah4oc[QGCM_HIP_MAXL];
+  double hoc[QGCM_HIP_MAXL];
+  double gpoc[QGCM_HIP_MAXL];                        /* nlo-1 used */
+  double amatoc[QGCM_HIP_MAXL * QGCM_HIP_MAXL];      /* amatoc(nlo,nlo)   eigmode.f:131-144 */
+  double ctl2moc[QGCM_HIP_MAXL * QGCM_HIP_MAXL];     /* ctl2moc(nlo,nlo)  eigmode.f:420-428 */
+  double ctm2loc[QGCM_HIP_MAXL * QGCM_HIP_MAXL];     /* ctm2loc(nlo,nlo) */
+  double rdm2oc[QGCM_HIP_MAXL];                      /* 1/Rd^2 per mode */
+  double aoc;                                        /* ocisubs: 1/dyo^2 (q-gcm.F:932) */
+} qgcm_hip_params;
+
+/* ---- life cycle -------------------------------------------------------- */
+/* device < 0: use the current HIP device. */
+int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, int device);
+int qgcm_hip_destroy(qgcm_hip_handle h);
+const char *qgcm_hip_last_error(void);
+int qgcm_hip_abi_version(void);
+
+/* yporel(nypo), bd2oc(nxto) [reference/FFTPACK ordering, q-gcm.F:933-954],
+ * ddynoc(nxpo,nypo).  Builds the device-side Thomas tables. */
+int qgcm_hip_set_grid(qgcm_hip_handle h, const double *yporel, const double *bd2oc,
+                      const double *ddynoc);
+
+/* Products of homsol (src/conhoms.F:544-641 box / 376-543 cyclic).
+ * box:    ochom(nxpo,nypo,nlo-1), cdiffo(nlo,nlo-1), cdhoc(nlo-1,nlo-1)
+ *         (the LU factors cdhlu/ipivch are recomputed internally).
+ * cyclic: pch1oc(nypo,nlo-1), pch2oc(nypo,nlo-1), pbhoc(nypo), aipcho(nlo-1),
+ *         hc1soc, hc2soc, hc1noc, hc2noc (nlo-1 each), hbsioc, aipbho. */
+int qgcm_hip_set_homog_box(qgcm_hip_handle h, const double *ochom, const double *cdiffo,
+                           const double *cdhoc);
+int qgcm_hip_set_homog_cyc(qgcm_hip_handle h, const double *pch1oc, const double *pch2oc,
+                           const double *pbhoc, const double *aipcho, const double *hc1soc,
+                           const double *hc2soc, const double *hc1noc, const double *hc2noc,
+                           double hbsioc, double aipbho);
+
+/* ---- state (MODULE ocstate) -------------------------------------------- */
+/* Any pointer may be NULL to skip that field. */
+int qgcm_hip_set_state(qgcm_hip_handle h, const double *po, const double *pom,
+                       const double *qo, const double *qom);
+int qgcm_hip_get_state(qgcm_hip_handle h, double *po, double *pom, double *qo, double *qom);
+/* wekpo(nxpo,nypo), entoc(nxpo,nypo), xon(nlo-1)  (written by xforc / oml) */
+int qgcm_hip_set_forcing(qgcm_hip_handle h, const double *wekpo, const double *entoc,
+                         const double *xon);
+/* cyclic only: txisoc, txinoc (xforc), enisoc/eninoc(nlo-1) (oml) */
+int qgcm_hip_set_cyc_forcing(qgcm_hip_handle h, double txisoc, double txinoc,
+                             const double *enisoc, const double *eninoc);
+/* constraint scalars of MODULE ochomog:
+ *   scal[0 .. nlo-2]        dpioc
+ *   scal[nlo-1 .. 2nlo-3]   dpiocp
+ *   then (cyclic) ocncs, ocncn, ocncsp, ocncnp (nlo each); box: ignored/zero.
+ * length 2*(nlo-1) + 4*nlo. */
+int qgcm_hip_set_scalars(qgcm_hip_handle h, const double *scal);
+int qgcm_hip_get_scalars(qgcm_hip_handle h, double *scal);
+/* diagnostics of the last ocinvq: xinhom(nlo); coef = hclco(nlo-1) [box] or
+ * c1(nlo-1), c2(nlo-1), c3 [cyclic] */
+int qgcm_hip_get_inv_diag(qgcm_hip_handle h, double *xinhom, double *coef);
+
+/* ---- the path ----------------------------------------------------------- */
+int qgcm_hip_qgostep(qgcm_hip_handle h);    /* replaces "call qgostep"        q-gcm.F:1243 */
+int qgcm_hip_ocinvq(qgcm_hip_handle h);     /* replaces "call ocinvq"         q-gcm.F:1246 */
+int qgcm_hip_ocqbdy(qgcm_hip_handle h);     /* replaces "call ocqbdy (qo,po)" q-gcm.F:1249 */
+int qgcm_hip_lf_average(qgcm_hip_handle h); /* ocean part of q-gcm.F:1328-1366 */
+/* n whole ocean steps starting at 1-based ocean step index s0: qgostep, ocinvq,
+ * ocqbdy and, when mod(s-1,25)==0, the averaging (nt = 1+(s-1)*nstr in
+ * q-gcm.F:1222,1328).  Uses captured HIP graphs. */
+int qgcm_hip_steps(qgcm_hip_handle h, int s0, int n);
+int qgcm_hip_sync(qgcm_hip_handle h);
+
+/* Helmholtz solve for homsol: wrk(nxpo,nypo) in/out, boc(nxto)
+ * (replaces hsbxoc / hscyoc, src/ocisubs.F:415-618). Synchronous. */
+int qgcm_hip_helmholtz(qgcm_hip_handle h, double *wrk, const double *boc);
+
+/* ---- measurement -------------------------------------------------------- */
+/* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
+ * the whole region, measured on the handle's stream. */
+int qgcm_hip_time_steps(qgcm_hip_handle h, int s0, int n, float *ms);
+/* Runs n steps eagerly with HIP events around every kernel launch and
+ * accumulates per-kernel totals: ms[i], launches[i] for i < *nk (in: capacity,
+ * out: number of kernel slots).  names[i] points to static strings. */
+int qgcm_hip_profile_steps(qgcm_hip_handle h, int s0, int n, double *ms, int *launches,
+                           const char **names, int *nk);
+/* device copy bandwidth probe (GB/s of read+write traffic) used as the
+ * "measured peak" beside the nominal 8 TB/s. */
+int qgcm_hip_copy_bandwidth(qgcm_hip_handle h, size_t bytes, int reps, double *gbps);
+/* HIP stream of the handle as an opaque pointer (hipStream_t). */
+void *qgcm_hip_stream(qgcm_hip_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QGCM_HIP_H */

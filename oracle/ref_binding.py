@@ -31,6 +31,9 @@ CONFIGS = {
 }
 
 
+_LOADED_CFG = None
+
+
 def lib_path(cfg):
     return os.path.join(REFDIR, "libqgcm_ref_%s.so" % cfg)
 
@@ -78,7 +81,15 @@ class RefLib:
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.cfg = cfg
-        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)  # MKL dlopens its kernels against libmkl_core symbols
+        # RTLD_GLOBAL: MKL dlopens its CPU-specific kernels against libmkl_core symbols.
+        # Consequence: every config exports the same Fortran module symbols (with
+        # different array sizes), so only ONE reference config may live in a process.
+        global _LOADED_CFG
+        if _LOADED_CFG not in (None, cfg):
+            raise RuntimeError("reference config %s already loaded in this process; use a subprocess for %s"
+                               % (_LOADED_CFG, cfg))
+        _LOADED_CFG = cfg
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         nx, ny, nl, cyc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self.lib.ref_dims(C.byref(nx), C.byref(ny), C.byref(nl), C.byref(cyc))
         self.nx, self.ny, self.nl, self.cyclic = nx.value, ny.value, nl.value, cyc.value

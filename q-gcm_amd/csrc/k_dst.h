@@ -1,0 +1,249 @@
+// k_dst.h - K3: per-row DST-I (box ocean) in LDS, replacing FFTPACK dsint.
+//
+// Reference: hsbxoc calls dsint(nxto-1, wrk(2,j)) for every row j=2..nypo-1,
+// once forward and once inverse per mode per step (src/ocisubs.F:461-463,
+// 494-499); dsint = pre-twiddle + length-(n+1) real FFT + running-sum
+// post-process (src/fftpack/newbihar/dsint.f:16-40, dsinti.f:15-25).
+//
+// Here one workgroup transforms TWO rows at once: the two pre-twiddled real
+// sequences of length N = n+1 = nxto are packed as real/imaginary parts of one
+// complex sequence, a Stockham mixed-radix (2,3,4,5) complex FFT of length N
+// runs in LDS, the two real spectra are separated by conjugate symmetry and
+// the FFTPACK post-process (including its running sum, done as a block scan)
+// produces both sine transforms.  The transform is its own inverse up to
+// 2N, absorbed by ftnorm in the Thomas kernel (ocisubs.F:440,486).
+//
+// Algorithmic traffic: one read + one write of the row (8 B each per point).
+#pragma once
+#include "qgcm_dev.h"
+
+#define DST_NT 128
+
+struct cplx {
+  double x, y;
+};
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// multiply by -i (forward quarter turn)
+__device__ __forceinline__ cplx cmni(cplx a) { return {a.y, -a.x}; }
+
+// One Stockham DIF stage of radix R over the whole length-N sequence:
+//   a_r = in[q + s*(p + m*r)],  b_u = sum_r a_r w_R^{ru},  out[q + s*(R*p + u)] = b_u * w_len^{p*u}
+template <int R>
+__device__ __forceinline__ void dst_stage(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int s, int m,
+                                          const double2 *__restrict__ tw, int twstep, int tid) {
+  const int nb = m * s;
+  for (int b = tid; b < nb; b += DST_NT) {
+    int p = b / s, q = b - p * s;
+    cplx a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = in[q + s * (p + m * r)];
+    cplx o[R];
+    if (R == 2) {
+      o[0] = cadd(a[0], a[1]);
+      o[1] = csub(a[0], a[1]);
+    } else if (R == 4) {
+      cplx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+      cplx t2 = cadd(a[1], a[3]), t3 = cmni(csub(a[1], a[3]));
+      o[0] = cadd(t0, t2);
+      o[2] = csub(t0, t2);
+      o[1] = cadd(t1, t3);
+      o[3] = csub(t1, t3);
+    } else if (R == 3) {
+      const double s3 = 0.86602540378443864676;
+      cplx t1 = cadd(a[1], a[2]);
+      cplx t2 = {a[0].x - 0.5 * t1.x, a[0].y - 0.5 * t1.y};
+      cplx d = csub(a[1], a[2]);
+      cplx t3 = {s3 * d.y, -s3 * d.x}; // -i * s3 * d
+      o[0] = cadd(a[0], t1);
+      o[1] = cadd(t2, t3);
+      o[2] = csub(t2, t3);
+    } else if (R == 5) {
+      const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+      const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+      cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
+      cplx t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+      o[0] = {a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y};
+      cplx m1 = {a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y};
+      cplx m2 = {a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y};
+      // -i*(s1*t3 + s2*t4), -i*(s2*t3 - s1*t4)
+      cplx n1 = {s1 * t3.y + s2 * t4.y, -(s1 * t3.x + s2 * t4.x)};
+      cplx n2 = {s2 * t3.y - s1 * t4.y, -(s2 * t3.x - s1 * t4.x)};
+      o[1] = cadd(m1, n1);
+      o[4] = csub(m1, n1);
+      o[2] = cadd(m2, n2);
+      o[3] = csub(m2, n2);
+    }
+    out[q + s * (R * p)] = o[0];
+#pragma unroll
+    for (int u = 1; u < R; ++u) {
+      double2 w = tw[p * u * twstep];
+      out[q + s * (R * p + u)] = cmul(o[u], cplx{w.x, w.y});
+    }
+  }
+}
+
+// generic odd prime radix (rare: only for grids whose nxto has a factor > 5)
+__device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict__ in, cplx *__restrict__ out, int N,
+                                                  int s, int m, const double2 *__restrict__ tw, int twstep, int tid) {
+  const int nb = m * s;
+  const int rstep = N / R;
+  for (int b = tid; b < nb; b += DST_NT) {
+    int p = b / s, q = b - p * s;
+    for (int u = 0; u < R; ++u) {
+      cplx acc = {0.0, 0.0};
+      for (int r = 0; r < R; ++r) {
+        double2 w = tw[((r * u) % R) * rstep];
+        acc = cadd(acc, cmul(in[q + s * (p + m * r)], cplx{w.x, w.y}));
+      }
+      double2 w = tw[p * u * twstep];
+      out[q + s * (R * p + u)] = cmul(acc, cplx{w.x, w.y});
+    }
+  }
+}
+
+// grid: (ceil(nrows/2), nlayers);  rows j = 2..ny-1  (nrows = ny-2)
+// dynamic LDS: 2*N cplx + 2*DST_NT doubles
+template <bool ROWSUM>
+__global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = P.N, n = N - 1;
+  cplx *A = reinterpret_cast<cplx *>(smem_raw);
+  cplx *B = A + N;
+  double *red = reinterpret_cast<double *>(B + N); // 2*DST_NT doubles
+  const int tid = threadIdx.x;
+  const int ny = P.g.ny, ldw = P.g.ldw;
+  const int m = blockIdx.y;
+  const int ja = 2 + 2 * blockIdx.x; // first row (1-based j)
+  const bool has_b = (ja + 1 <= ny - 1);
+  double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
+  double *rowb = rowa + ldw;
+
+  // ---- pre-twiddle (dsint.f:19-33): element a[k], k=1..n lives at index k-1
+  const int ns2 = n / 2;
+  if (tid == 0) A[0] = {0.0, 0.0};
+  for (int k = 1 + tid; k <= ns2; k += DST_NT) {
+    double xa = rowa[k - 1], xac = rowa[n - k];
+    double xb = has_b ? rowb[k - 1] : 0.0, xbc = has_b ? rowb[n - k] : 0.0;
+    double sn = P.sintab[k];
+    double t1a = xa - xac, t2a = sn * (xa + xac);
+    double t1b = xb - xbc, t2b = sn * (xb + xbc);
+    A[k] = {t1a + t2a, t1b + t2b};
+    A[N - k] = {t2a - t1a, t2b - t1b};
+  }
+  if ((n & 1) && tid == 0) {
+    int kc = ns2 + 1;
+    double xa = rowa[kc - 1], xb = has_b ? rowb[kc - 1] : 0.0;
+    A[kc] = {4.0 * xa, 4.0 * xb};
+  }
+  __syncthreads();
+
+  // ---- complex FFT of length N, Stockham autosort ----------------------
+  cplx *in = A, *out = B;
+  int s = 1, len = N;
+  for (int f = 0; f < P.nfac; ++f) {
+    const int R = P.fac[f];
+    const int mm = len / R;
+    const int twstep = N / len;
+    switch (R) {
+      case 2: dst_stage<2>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 3: dst_stage<3>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 4: dst_stage<4>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 5: dst_stage<5>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      default: dst_stage_generic(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+    }
+    __syncthreads();
+    cplx *t = in;
+    in = out;
+    out = t;
+    s *= R;
+    len = mm;
+  }
+  const cplx *Z = in;
+
+  // ---- separate the two real spectra and post-process (dsint.f:37-44) ----
+  //   Y_k  = (Z_k + conj Z_{N-k})/2      (row a)
+  //   Y'_k = (Z_k - conj Z_{N-k})/(2i)   (row b)
+  //   b[1] = 0.5 Re Y_0 ; b[2k] = -Im Y_k ; b[2k+1] = b[2k-1] + Re Y_k
+  const int K = (n - 1) / 2;              // odd outputs b[2k+1], k=1..K
+  const int chunk = (K + DST_NT - 1) / DST_NT;
+  const int k0 = 1 + tid * chunk;
+  double suma = 0.0, sumb = 0.0;
+  for (int k = k0; k < k0 + chunk && k <= K; ++k) {
+    cplx z1 = Z[k], z2 = Z[N - k];
+    suma += 0.5 * (z1.x + z2.x);
+    sumb += 0.5 * (z1.y + z2.y);
+  }
+  red[tid] = suma;
+  red[DST_NT + tid] = sumb;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over the DST_NT partials (both rows)
+  for (int off = 1; off < DST_NT; off <<= 1) {
+    double va = 0.0, vb = 0.0;
+    if (tid >= off) {
+      va = red[tid - off];
+      vb = red[DST_NT + tid - off];
+    }
+    __syncthreads();
+    if (tid >= off) {
+      red[tid] += va;
+      red[DST_NT + tid] += vb;
+    }
+    __syncthreads();
+  }
+  const double b1a = 0.5 * Z[0].x, b1b = 0.5 * Z[0].y;
+  double runa = b1a + (tid > 0 ? red[tid - 1] : 0.0);
+  double runb = b1b + (tid > 0 ? red[DST_NT + tid - 1] : 0.0);
+  double rsa = 0.0, rsb = 0.0; // row sums (inverse pass: area integral, intsubs.f:78-133)
+  if (tid == 0) {
+    rowa[0] = b1a;
+    if (has_b) rowb[0] = b1b;
+    rsa += b1a;
+    rsb += b1b;
+  }
+  for (int k = k0; k < k0 + chunk && k <= K; ++k) {
+    cplx z1 = Z[k], z2 = Z[N - k];
+    double rea = 0.5 * (z1.x + z2.x), ima = 0.5 * (z1.y - z2.y);
+    double reb = 0.5 * (z1.y + z2.y), imb = -0.5 * (z1.x - z2.x);
+    runa += rea;
+    runb += reb;
+    rowa[2 * k - 1] = -ima; // b[2k]
+    rowa[2 * k] = runa;     // b[2k+1]
+    rsa += runa - ima;
+    if (has_b) {
+      rowb[2 * k - 1] = -imb;
+      rowb[2 * k] = runb;
+      rsb += runb - imb;
+    }
+  }
+  // n even: the last even output b[n] = -Im Y_{n/2} has no odd partner
+  if (!(n & 1) && tid == DST_NT - 1) {
+    int k = n / 2;
+    cplx z1 = Z[k], z2 = Z[N - k];
+    double ima = 0.5 * (z1.y - z2.y), imb = -0.5 * (z1.x - z2.x);
+    rowa[n - 1] = -ima;
+    rsa += -ima;
+    if (has_b) {
+      rowb[n - 1] = -imb;
+      rsb += -imb;
+    }
+  }
+  if (ROWSUM) {
+    __syncthreads();
+    red[tid] = rsa;
+    red[DST_NT + tid] = rsb;
+    __syncthreads();
+    for (int off = DST_NT / 2; off > 0; off >>= 1) {
+      if (tid < off) {
+        red[tid] += red[tid + off];
+        red[DST_NT + tid] += red[DST_NT + tid + off];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      P.rowsum[(long)m * ny + (ja - 1)] = red[0];
+      if (has_b) P.rowsum[(long)m * ny + ja] = red[DST_NT];
+    }
+  }
+}

@@ -1,0 +1,194 @@
+// k_misc.h - constraint solve, mode->layer unpack, boundary PV, LF averaging.
+#pragma once
+#include "qgcm_dev.h"
+
+#define CS_NT 256
+
+// ---------------------------------------------------------------------------
+// K5+K6 (box): area integrals of the inhomogeneous solutions + mass
+// constraints.  Reference: xintp per mode (src/ocisubs.F:160, src/intsubs.f:
+// 78-133; boundary values of wrk are zero so the trapezoid weights reduce to
+// the plain interior sum delivered per row by the inverse DST kernel), then
+// dpioc update, rhs and the (nlo-1)x(nlo-1) solve with DGETRS + DGERFS
+// (src/ocisubs.F:333-370).  One workgroup; fixed-order tree reduction, so
+// the result is deterministic (the reference's OpenMP reduction is not).
+// ---------------------------------------------------------------------------
+__device__ inline void qg_lu_solve(int n, const double *lu, const int *piv, double *b) {
+  for (int k = 0; k < n; ++k)
+    if (piv[k] != k) {
+      double t = b[k];
+      b[k] = b[piv[k]];
+      b[piv[k]] = t;
+    }
+  for (int k = 0; k < n; ++k)
+    for (int i = k + 1; i < n; ++i) b[i] -= lu[i + n * k] * b[k];
+  for (int k = n - 1; k >= 0; --k) {
+    b[k] /= lu[k + n * k];
+    for (int i = 0; i < k; ++i) b[i] -= lu[i + n * k] * b[k];
+  }
+}
+
+__device__ inline double qg_block_sum(double v, double *red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int off = CS_NT / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(CS_NT) void k_constr_box(const QgConstrParams P) {
+  __shared__ double red[CS_NT];
+  __shared__ double xin[QG_MAXL];
+  const int tid = threadIdx.x;
+  const int nl = P.g.nl, ny = P.g.ny;
+  for (int m = 0; m < nl; ++m) {
+    double s = 0.0;
+    for (int j = 1 + tid; j <= ny - 2; j += CS_NT) s += P.rowsum[(long)m * ny + j];
+    double tot = qg_block_sum(s, red, tid);
+    if (tid == 0) xin[m] = tot * P.dxo * P.dyo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    QgScalars *sc = P.sc;
+    const int n1 = nl - 1;
+    double rhs[QG_MAXL], x[QG_MAXL], r[QG_MAXL], w[QG_MAXL];
+    for (int m = 0; m < nl; ++m) sc->xinhom[m] = xin[m];
+    for (int k = 0; k < n1; ++k) {
+      double aient = (k == 0) ? sc->xon[0] : 0.0;
+      double aitmp = sc->dpioc[k];
+      sc->dpioc[k] = sc->dpiocp[k] - P.tdto * P.gpoc[k] * aient;
+      sc->dpiocp[k] = aitmp;
+      double rhsum = 0.0;
+      for (int m = 0; m < nl; ++m) rhsum = rhsum + P.cs.cdiffo[m + nl * k] * xin[m];
+      rhs[k] = sc->dpioc[k] - rhsum;
+      x[k] = rhs[k];
+    }
+    qg_lu_solve(n1, P.cs.cdhlu, P.cs.ipiv, x);
+    // iterative refinement with DGERFS's stopping rule (ITMAX = 5)
+    const double eps = 1.1102230246251565e-16, safmin = 2.2250738585072014e-308;
+    const double safe1 = (n1 + 1) * safmin, safe2 = safe1 / eps;
+    double lstres = 3.0;
+    for (int count = 1;; ++count) {
+      for (int i = 0; i < n1; ++i) {
+        double s = rhs[i], t = fabs(rhs[i]);
+        for (int j = 0; j < n1; ++j) {
+          s -= P.cs.cdhoc[i + n1 * j] * x[j];
+          t += fabs(P.cs.cdhoc[i + n1 * j]) * fabs(x[j]);
+        }
+        r[i] = s;
+        w[i] = t;
+      }
+      double berr = 0.0;
+      for (int i = 0; i < n1; ++i) {
+        double v = (w[i] > safe2) ? fabs(r[i]) / w[i] : (fabs(r[i]) + safe1) / (w[i] + safe1);
+        if (v > berr) berr = v;
+      }
+      if (berr > eps && 2.0 * berr <= lstres && count <= 5) {
+        qg_lu_solve(n1, P.cs.cdhlu, P.cs.ipiv, r);
+        for (int i = 0; i < n1; ++i) x[i] += r[i];
+        lstres = berr;
+      } else
+        break;
+    }
+    for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K7: add homogeneous solutions, modes -> layers (src/ocisubs.F:377-401).
+// The reference also copies po -> pom here; the p buffers rotate instead, so
+// the new po is written over the old pom and the names are swapped by the host.
+// Traffic: read wrk (nl) + ochom (nl-1), write po (nl).
+// ---------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P) {
+  const int nx = P.g.nx, ny = P.g.ny;
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const int gj = blockIdx.y + 1;
+  if (gi > nx || gj > ny) return;
+  const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
+  const bool inner = (gi >= 2 && gi <= nx - 1 && gj >= 2 && gj <= ny - 1);
+  const long ow = (long)(gj - 1) * P.g.ldw + (gi - 2);
+  double pm[NL];
+  pm[0] = inner ? P.wrk[ow] : 0.0;
+#pragma unroll
+  for (int m = 1; m < NL; ++m) {
+    double wv = inner ? P.wrk[P.g.wstride * m + ow] : 0.0;
+    pm[m] = wv + P.sc->hclco[m - 1] * P.ochom[P.g.fstride * (m - 1) + o];
+  }
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    double pl = 0.0;
+#pragma unroll
+    for (int m = 0; m < NL; ++m) pl = pl + P.ctm2l[m + NL * k] * pm[m];
+    P.pnew[P.g.fstride * k + o] = pl;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K8: PV on the solid boundaries from the new pressure (src/vorsubs.F:245-388)
+// grid: x covers max(nx,ny) points; blockIdx.y = side (0 S, 1 N, 2 W, 3 E); z = layer
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ocqbdy(const QgBdyParams P) {
+  const int nx = P.g.nx, ny = P.g.ny, nl = P.g.nl, ldx = P.g.ldx;
+  const long fs = P.g.fstride;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const int side = blockIdx.y;
+  const int k = blockIdx.z;
+  int gi, gj, ii, jj; // boundary point, its inward neighbour
+  if (side < 2) {
+    if (t > nx) return;
+    gi = t; ii = t;
+    gj = (side == 0) ? 1 : ny;
+    jj = (side == 0) ? 2 : ny - 1;
+  } else {
+    if (P.g.cyc) return;
+    if (t < 2 || t > ny - 1) return;
+    gj = t; jj = t;
+    gi = (side == 2) ? 1 : nx;
+    ii = (side == 2) ? 2 : nx - 1;
+  }
+  const long ob = (long)(gj - 1) * ldx + (gi - 1);
+  const long oi = (long)(jj - 1) * ldx + (ii - 1);
+  const double *po = P.po;
+  double pb = po[fs * k + ob];
+  double ap;
+  if (k == 0) ap = P.f0A[0 + nl * 0] * pb + P.f0A[0 + nl * 1] * po[fs * 1 + ob];
+  else if (k == nl - 1) ap = P.f0A[k + nl * (k - 1)] * po[fs * (k - 1) + ob] + P.f0A[k + nl * k] * pb;
+  else ap = P.f0A[k + nl * (k - 1)] * po[fs * (k - 1) + ob] + P.f0A[k + nl * k] * pb + P.f0A[k + nl * (k + 1)] * po[fs * (k + 1) + ob];
+  double q = P.bcfaco_f0 * (po[fs * k + oi] - pb) - ap + P.beta * P.yporel[gj - 1];
+  if (k == nl - 1) q = q + P.ddynoc[ob];
+  P.qo[fs * k + ob] = q;
+}
+
+// ---------------------------------------------------------------------------
+// K9: leapfrog time-level averaging (src/q-gcm.F:1328-1366, ocean part)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lf_average(double *qo, const double *qom, double *po, const double *pom,
+                                                     long n, QgScalars *sc, int nl, int cyc) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    qo[i] = 0.5 * (qo[i] + qom[i]);
+    po[i] = 0.5 * (po[i] + pom[i]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < nl - 1; ++k) sc->dpioc[k] = 0.5 * (sc->dpioc[k] + sc->dpiocp[k]);
+    if (cyc)
+      for (int k = 0; k < nl; ++k) {
+        sc->ocncs[k] = 0.5 * (sc->ocncs[k] + sc->ocncsp[k]);
+        sc->ocncn[k] = 0.5 * (sc->ocncn[k] + sc->ocncnp[k]);
+      }
+  }
+}
+
+// device-to-device copy probe for the "measured peak" of the roofline
+__global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}

@@ -1,0 +1,195 @@
+// k_tend.h - K1: PV tendency + leapfrog + layer->mode projection, one pass.
+//
+// Replaces, per ocean step (reference file:line):
+//   del2p = Del^2(pom) with mixed BCs            src/qgosubs.F:86-130
+//   ocadif: d4p, d6p, Arakawa 9-pt J(q,p), dqdt  src/qgosubs.F:306-400
+//   forcing / bottom drag / leapfrog             src/qgosubs.F:173-219
+//   ocinvq projection onto modes                 src/ocisubs.F:117-139
+//
+// One workgroup owns a TX x TY tile of p-points for ALL layers.  Per layer
+// the radius-3 halo of pom and the radius-1 halos of po, qo are staged in
+// LDS, Del^2 / Del^4 are built in LDS with the reference's boundary rules,
+// and each thread finishes Del^6 + Jacobian for its points in registers.
+// Expression association order is the reference's, and the library is built
+// with -ffp-contract=off, so qgostep reproduces the CPU reference bit for bit.
+//
+// Algorithmic HBM traffic: read pom,po,qo,qom (4 nl) + wekpo,entoc,ddynoc (3),
+// write qo (nl) + wrk (nl)  ->  (6 nl + 3) N doubles = 21 N for nl = 3
+// (SURVEY 8d counts 24 N because the reference also rewrites qom; here the
+// q buffers rotate instead).
+#pragma once
+#include "qgcm_dev.h"
+
+#define TEND_TX 64
+#define TEND_TY 8
+#define TEND_NT 256
+
+template <bool CYC>
+__device__ __forceinline__ int tend_wrap(int gi, int nxt) {
+  if (CYC) {
+    if (gi < 1) gi += nxt;
+    else if (gi > nxt) gi -= nxt;
+  }
+  return gi;
+}
+
+template <int NL, bool CYC>
+__global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
+  constexpr int TX = TEND_TX, TY = TEND_TY;
+  constexpr int W3 = TX + 6, H3 = TY + 6; // pom tile, halo 3
+  constexpr int W2 = TX + 4, H2 = TY + 4; // d2 tile, halo 2
+  constexpr int W1 = TX + 2, H1 = TY + 2; // d4 / po / qo tiles, halo 1
+  __shared__ double sp[H3 * W3];
+  __shared__ double sd2[H2 * W2];
+  __shared__ double sd4[H1 * W1];
+  __shared__ double spo[H1 * W1];
+  __shared__ double sqo[H1 * W1];
+
+  const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt, ldx = P.g.ldx;
+  const long fs = P.g.fstride;
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * TX + 1; // first global i of the tile (1-based)
+  const int j0 = blockIdx.y * TY + 1;
+  const int tx = tid % TX;
+  const int ty0 = tid / TX; // 0..3
+  constexpr int RPT = TY / (TEND_NT / TX); // rows per thread
+  const double bcf = P.bcfaco, dxom2 = P.dxom2;
+
+  double dq[NL][RPT];
+  double d2bot[RPT];
+
+  for (int k = 0; k < NL; ++k) {
+    const double *pom = P.pom + fs * k;
+    const double *po = P.po + fs * k;
+    const double *qo = P.qo + fs * k;
+    // ---- stage tiles -------------------------------------------------
+    for (int idx = tid; idx < H3 * W3; idx += TEND_NT) {
+      int lx = idx % W3, ly = idx / W3;
+      int gi = i0 - 3 + lx, gj = j0 - 3 + ly;
+      double v = 0.0;
+      if (gj >= 1 && gj <= ny) {
+        if (CYC) {
+          if (gi >= -2 && gi <= nx + 3) v = pom[(long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1)];
+        } else if (gi >= 1 && gi <= nx) {
+          v = pom[(long)(gj - 1) * ldx + (gi - 1)];
+        }
+      }
+      sp[idx] = v;
+    }
+    for (int idx = tid; idx < H1 * W1; idx += TEND_NT) {
+      int lx = idx % W1, ly = idx / W1;
+      int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
+      double vp = 0.0, vq = 0.0;
+      if (gj >= 1 && gj <= ny) {
+        bool ok = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
+        if (ok) {
+          long o = (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1);
+          vp = po[o];
+          vq = qo[o];
+        }
+      }
+      spo[idx] = vp;
+      sqo[idx] = vq;
+    }
+    __syncthreads();
+    // ---- Del^2(pom) on the halo-2 region (qgosubs.F:94-127) ----------
+    for (int idx = tid; idx < H2 * W2; idx += TEND_NT) {
+      int lx = idx % W2, ly = idx / W2;
+      int gi = i0 - 2 + lx, gj = j0 - 2 + ly;
+      const double *c = &sp[(ly + 1) * W3 + (lx + 1)];
+      double v = 0.0;
+      bool inx = CYC ? (gi >= -1 && gi <= nx + 2) : (gi >= 1 && gi <= nx);
+      if (gj >= 1 && gj <= ny && inx) {
+        if (gj == 1) v = bcf * (c[W3] - c[0]);
+        else if (gj == ny) v = bcf * (c[-W3] - c[0]);
+        else if (!CYC && gi == 1) v = bcf * (c[1] - c[0]);
+        else if (!CYC && gi == nx) v = bcf * (c[-1] - c[0]);
+        else v = (c[-W3] + c[-1] + c[1] + c[W3] - 4.0 * c[0]) * dxom2;
+      }
+      sd2[idx] = v;
+    }
+    __syncthreads();
+    // ---- Del^4 on the halo-1 region (qgosubs.F:310-341) ---------------
+    for (int idx = tid; idx < H1 * W1; idx += TEND_NT) {
+      int lx = idx % W1, ly = idx / W1;
+      int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
+      const double *c = &sd2[(ly + 1) * W2 + (lx + 1)];
+      double v = 0.0;
+      bool inx = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
+      if (gj >= 1 && gj <= ny && inx) {
+        if (gj == 1) v = bcf * (c[W2] - c[0]);
+        else if (gj == ny) v = bcf * (c[-W2] - c[0]);
+        else if (!CYC && gi == 1) v = bcf * (c[1] - c[0]);
+        else if (!CYC && gi == nx) v = bcf * (c[-1] - c[0]);
+        else v = dxom2 * (c[-W2] + c[-1] + c[1] + c[W2] - 4.0 * c[0]);
+      }
+      sd4[idx] = v;
+    }
+    __syncthreads();
+    // ---- Del^6 + Jacobian at the tile's own points (qgosubs.F:349-399)
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      int ly = ty0 + r * (TEND_NT / TX);
+      int gi = i0 + tx, gj = j0 + ly;
+      double val = 0.0;
+      bool interior = (gj >= 2 && gj <= ny - 1) && (CYC ? (gi >= 1 && gi <= nx) : (gi >= 2 && gi <= nx - 1));
+      if (interior) {
+        const double *d4 = &sd4[(ly + 1) * W1 + (tx + 1)];
+        const double *p = &spo[(ly + 1) * W1 + (tx + 1)];
+        const double *q = &sqo[(ly + 1) * W1 + (tx + 1)];
+        double d6p = dxom2 * (d4[-W1] + d4[-1] + d4[1] + d4[W1] - 4.0 * d4[0]);
+        double diffus = P.ah2fac[k] * d4[0] - P.ah4fac[k] * d6p;
+        double jac = (q[1] - q[-1]) * (p[W1] - p[-W1]) + (q[-W1] - q[W1]) * (p[1] - p[-1]) +
+                     q[1] * (p[W1 + 1] - p[-W1 + 1]) - q[-1] * (p[W1 - 1] - p[-W1 - 1]) -
+                     q[W1] * (p[W1 + 1] - p[W1 - 1]) + q[-W1] * (p[-W1 + 1] - p[-W1 - 1]) +
+                     p[W1] * (q[W1 + 1] - q[W1 - 1]) - p[-W1] * (q[-W1 + 1] - q[-W1 - 1]) -
+                     p[1] * (q[W1 + 1] - q[-W1 + 1]) + p[-1] * (q[W1 - 1] - q[-W1 - 1]);
+        val = P.adfaco * jac + diffus;
+      }
+      dq[k][r] = val;
+      if (k == NL - 1) d2bot[r] = sd2[(ly + 2) * W2 + (tx + 2)];
+    }
+    __syncthreads();
+  }
+
+  // ---- forcing, bottom drag, leapfrog, projection ----------------------
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    int ly = ty0 + r * (TEND_NT / TX);
+    int gi = i0 + tx, gj = j0 + ly;
+    if (gi > nx || gj > ny) continue;
+    long o = (long)(gj - 1) * ldx + (gi - 1);
+    if (gj == 1 || gj == ny) {
+      // rows not stepped: the new-qo buffer keeps qo (qgosubs.F:214-219)
+#pragma unroll
+      for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = P.qo[fs * k + o];
+      continue;
+    }
+    double ent = P.entoc[o];
+    double qdot[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) qdot[k] = dq[k][r];
+    qdot[0] = dq[0][r] + P.fohfac[0] * (P.wekpo[o] - ent);
+    qdot[1] = dq[1][r] + P.fohfac[1] * ent;
+    qdot[NL - 1] = qdot[NL - 1] - P.bdrfac * d2bot[r];
+    double ql[NL];
+    double betay = P.beta * P.yporel[gj - 1];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      double qn = P.qnew[fs * k + o] + P.tdto * qdot[k]; // qom + tdto*qdot
+      P.qnew[fs * k + o] = qn;
+      ql[k] = qn - betay;
+    }
+    ql[NL - 1] = ql[NL - 1] - P.ddynoc[o];
+    int c = CYC ? gi - 1 : gi - 2;
+    if (c >= 0 && c < P.g.nk) {
+#pragma unroll
+      for (int m = 0; m < NL; ++m) {
+        double qm = 0.0;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) qm = qm + P.ctl2m[k + NL * m] * ql[k];
+        P.wrk[P.g.wstride * m + (long)(gj - 1) * P.g.ldw + c] = P.fnot * qm;
+      }
+    }
+  }
+}

@@ -1,0 +1,107 @@
+// k_thomas.h - K4: batched constant-coefficient tridiagonal solves along y.
+//
+// Reference: for every wavenumber i the system
+//     aoc*u(j-1) + boc(i)*u(j) + aoc*u(j+1) = rhs(i,j),  j = 2..nypo-1
+// is solved by the Thomas algorithm (src/ocisubs.F:470-488 box, 575-593
+// cyclic) and scaled by ftnorm.  The pivots betinv(j) = 1/(boc - aoc*gam(j))
+// depend only on (boc, j): they are tabulated once (host, same recurrence and
+// rounding as the reference) in `bet`, which removes every divide.
+//
+// Parallel formulation: both sweeps are first-order linear recurrences
+//     forward : u_r = (w_r - aoc*u_{r-1}) * bet_r
+//     backward: v_r = u_r - aoc*bet_r * v_{r+1}
+// The rows are cut into 64 chunks of R rows; lanes hold 16 consecutive
+// wavenumbers (one 128-B line) x 4 chunks per wave, a workgroup of 1024
+// threads covers a whole column block.  Each thread keeps its R rows in
+// registers, computes the chunk's affine map (C, D) with zero inflow, the
+// maps are composed through LDS, and the sweep is re-run from the true
+// inflow - so each row is read once and written once.
+//
+// Algorithmic traffic: read w + write u (16 B per point); the pivot table adds
+// 8 B per point of re-read (cache resident for the 5 km grid).
+#pragma once
+#include "qgcm_dev.h"
+
+#define TH_KW 16   // wavenumbers per workgroup (128-B line)
+#define TH_NC 64   // chunks per column
+#define TH_NT (TH_KW * TH_NC)
+
+// grid: (ceil(nk/16), nlayers)
+template <int R>
+__global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
+  __shared__ double sC[TH_NC][TH_KW];
+  __shared__ double sD[TH_NC][TH_KW];
+  __shared__ double sIn[TH_NC][TH_KW];
+  const int tid = threadIdx.x;
+  const int kk = tid % TH_KW;
+  const int c = tid / TH_KW;
+  const int k = blockIdx.x * TH_KW + kk;
+  const int m = blockIdx.y;
+  const int nr = P.g.ny - 2; // rows j=2..ny-1  <->  r = 0..nr-1
+  const int ldw = P.g.ldw;
+  const bool kok = k < P.g.nk;
+  const double a = P.aoc;
+  double *wcol = P.wrk + P.g.wstride * m + (long)ldw + k;      // row j=2
+  const double *bcol = P.bet + P.g.wstride * m + (long)ldw + k;
+  const int r0 = c * R;
+
+  double w[R], b[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    int r = r0 + t;
+    bool ok = kok && r < nr;
+    w[t] = ok ? wcol[(long)r * ldw] : 0.0;
+    b[t] = ok ? bcol[(long)r * ldw] : 0.0;
+  }
+  // ---- forward: local affine map (zero inflow) ---------------------------
+  double C = 0.0, D = 1.0;
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    C = (w[t] - a * C) * b[t];
+    D = -a * b[t] * D;
+  }
+  sC[c][kk] = C;
+  sD[c][kk] = D;
+  __syncthreads();
+  if (tid < TH_KW) {
+    double u = 0.0;
+    for (int cc = 0; cc < TH_NC; ++cc) {
+      sIn[cc][tid] = u;
+      u = sC[cc][tid] + sD[cc][tid] * u;
+    }
+  }
+  __syncthreads();
+  double u = sIn[c][kk];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    u = (w[t] - a * u) * b[t];
+    w[t] = u;
+  }
+  // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
+  C = 0.0;
+#pragma unroll
+  for (int t = R - 1; t >= 0; --t) C = w[t] - a * b[t] * C;
+  __syncthreads();
+  sC[c][kk] = C; // D is the same product as in the forward sweep
+  __syncthreads();
+  if (tid < TH_KW) {
+    double v = 0.0;
+    for (int cc = TH_NC - 1; cc >= 0; --cc) {
+      sIn[cc][tid] = v;
+      v = sC[cc][tid] + sD[cc][tid] * v;
+    }
+  }
+  __syncthreads();
+  double v = sIn[c][kk];
+  const double ft = P.ftnorm;
+#pragma unroll
+  for (int t = R - 1; t >= 0; --t) {
+    v = w[t] - a * b[t] * v;
+    w[t] = v;
+  }
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    int r = r0 + t;
+    if (kok && r < nr) wcol[(long)r * ldw] = ft * w[t];
+  }
+}

@@ -1,0 +1,114 @@
+// qgcm_dev.h - shared device/host declarations for the MI355X (gfx950) ocean path.
+//
+// Data layout in HBM (all fp64):
+//   field(i,j,k)  p-grid fields po,pom,qo,qom(nxpo,nypo,nlo), wekpo, entoc,
+//                 ddynoc(nxpo,nypo), ochom(nxpo,nypo,nlo-1):
+//                 element (i,j,k) 1-based at  (i-1) + ldx*((j-1) + nypo*(k-1)),
+//                 ldx = nxpo rounded up to 16 doubles (rows start 128-B aligned).
+//   wrk(c,j,m)    spectral/physical work array of the Helmholtz solve, one
+//                 128-B aligned row of ldw doubles per (j,m):
+//                 box:    c = i-2  for interior i=2..nxpo-1 (nk = nxto-1 sine coeffs)
+//                 cyclic: c = i-1  for i=1..nxto            (nk = nxto, own spectral order)
+//   bet(c,j,m)    Thomas table betinv (same layout as wrk), time-invariant.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/qgcm_hip.h"
+
+#define QG_MAXL QGCM_HIP_MAXL
+#define QG_MAXFAC 24
+
+// scalars that live on the device between kernels (MODULE ochomog state)
+struct QgScalars {
+  double dpioc[QG_MAXL], dpiocp[QG_MAXL], xon[QG_MAXL];
+  double xinhom[QG_MAXL], hclco[QG_MAXL];
+  // cyclic
+  double ocncs[QG_MAXL], ocncn[QG_MAXL], ocncsp[QG_MAXL], ocncnp[QG_MAXL];
+  double enisoc[QG_MAXL], eninoc[QG_MAXL];
+  double ajisoc[QG_MAXL], ajinoc[QG_MAXL], ap3soc[QG_MAXL], ap3noc[QG_MAXL], ap5soc[QG_MAXL], ap5noc[QG_MAXL];
+  double txisoc, txinoc, bdrins, bdrinn;
+  double c1[QG_MAXL], c2[QG_MAXL], c3;
+};
+
+// constants of the box / cyclic constraint solve (host-prepared)
+struct QgConstr {
+  double cdiffo[QG_MAXL * QG_MAXL]; // (nl, nl-1)
+  double cdhoc[QG_MAXL * QG_MAXL];  // (nl-1, nl-1)
+  double cdhlu[QG_MAXL * QG_MAXL];  // LU of cdhoc
+  int ipiv[QG_MAXL];
+  double aipcho[QG_MAXL], hc1soc[QG_MAXL], hc2soc[QG_MAXL], hc1noc[QG_MAXL], hc2noc[QG_MAXL];
+  double hbsioc, aipbho;
+};
+
+// geometry shared by all kernels
+struct QgGeom {
+  int nx, ny, nl, cyc;
+  int nxt;        // nxto = nx-1
+  int nk;         // spectral coefficients per row
+  int ldx, ldw;   // row pitches (doubles)
+  long fstride;   // ldx*ny
+  long wstride;   // ldw*ny
+};
+
+struct QgTendParams {
+  QgGeom g;
+  const double *pom, *po, *qo; // read (halo)
+  double *qnew;                // in: qom, out: new qo (same buffer)
+  const double *wekpo, *entoc, *ddynoc, *yporel;
+  double *wrk;
+  QgScalars *sc;
+  double *bsum; // cyclic boundary line-sum partials
+  double adfaco, bcfaco, dxom2, tdto, bdrfac, fnot, beta;
+  double fohfac[QG_MAXL], ah2fac[QG_MAXL], ah4fac[QG_MAXL];
+  double ctl2m[QG_MAXL * QG_MAXL]; // (k,m) at k + nl*m
+};
+
+struct QgDstParams {
+  QgGeom g;
+  double *wrk;            // in/out rows
+  const double2 *twid;    // exp(-2 pi i t / N), t = 0..N-1
+  const double *sintab;   // 2 sin(k pi / N), k = 0..N/2
+  double *rowsum;         // (ny, nl) row sums (inverse pass only) or nullptr
+  int N;                  // complex FFT length (= nxto for the box DST)
+  int nfac;
+  int fac[QG_MAXFAC];
+  int nlayers;            // layers to process (nl, or 1 for helmholtz())
+};
+
+struct QgThomasParams {
+  QgGeom g;
+  double *wrk;
+  const double *bet; // betinv table
+  double aoc, ftnorm;
+  int nlayers;
+};
+
+struct QgUnpackParams {
+  QgGeom g;
+  const double *wrk;
+  const double *ochom;
+  double *pnew; // old pom buffer, receives the new po
+  const QgScalars *sc;
+  const double *pch1, *pch2, *pbh; // cyclic (ny, nl-1), (ny)
+  double ctm2l[QG_MAXL * QG_MAXL]; // (m,k) at m + nl*k
+};
+
+struct QgBdyParams {
+  QgGeom g;
+  const double *po;
+  double *qo;
+  const double *ddynoc, *yporel;
+  double bcfaco_f0; // bccooc*dxom2/(0.5*bccooc+1)/fnot
+  double beta;
+  double f0A[QG_MAXL * QG_MAXL]; // fnot*amatoc(k,l) at k + nl*l
+};
+
+struct QgConstrParams {
+  QgGeom g;
+  const double *rowsum;
+  const double *wrk;
+  QgScalars *sc;
+  QgConstr cs;
+  double dxo, dyo, tdto, fnot;
+  double gpoc[QG_MAXL], hoc[QG_MAXL];
+  double ctl2m[QG_MAXL * QG_MAXL], ctm2l[QG_MAXL * QG_MAXL];
+};

@@ -1,0 +1,756 @@
+// qgcm_hip.hip - C ABI (include/qgcm_hip.h) over the gfx950 kernels.
+//
+// One HIP stream per handle; state stays resident in HBM; the q and p time
+// levels rotate between two buffers each instead of being copied
+// (reference: qom<-qo in src/qgosubs.F:201-206, pom<-po in src/ocisubs.F:392).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "qgcm_dev.h"
+#include "k_tend.h"
+#include "k_dst.h"
+#include "k_thomas.h"
+#include "k_misc.h"
+
+static thread_local char g_err[512] = "";
+
+#define QG_FAIL(...)                             \
+  do {                                           \
+    snprintf(g_err, sizeof(g_err), __VA_ARGS__); \
+    return 1;                                    \
+  } while (0)
+
+#define HIPCHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) QG_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+enum { KN_TEND = 0, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_COUNT };
+static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_dst_fwd", "k_thomas", "k_dst_inv",
+                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average"};
+
+struct qgcm_hip_ctx {
+  qgcm_hip_params prm;
+  QgGeom g;
+  int device;
+  hipStream_t stream;
+  double *p[2], *q[2];
+  int ip, iq; // p[ip] = po, p[ip^1] = pom ; q[iq] = qo, q[iq^1] = qom
+  double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
+  double *wrk, *bet, *bet_tmp, *rowsum;
+  double *pch1, *pch2, *pbh;
+  QgScalars *sc;
+  double2 *twid;
+  double *sintab;
+  int fftN, nfac, fac[QG_MAXFAC];
+  QgConstr cs;
+  bool grid_set, homog_set;
+  std::vector<double> bd2oc;
+  // profiling
+  bool profiling;
+  hipEvent_t ev0, ev1;
+  double kms[KN_COUNT];
+  int klaunch[KN_COUNT];
+  // graphs keyed by (ip, iq, phase)
+  std::map<int, hipGraphExec_t> graphs;
+  size_t dst_lds;
+};
+
+static const int kGraphBlock = 50;
+
+extern "C" const char *qgcm_hip_last_error(void) { return g_err; }
+extern "C" int qgcm_hip_abi_version(void) { return QGCM_HIP_ABI_VERSION; }
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int factorize(int n, int *fac) {
+  int nf = 0;
+  static const int tr[4] = {4, 2, 3, 5};
+  for (int t = 0; t < 4; ++t)
+    while (n % tr[t] == 0) {
+      fac[nf++] = tr[t];
+      n /= tr[t];
+    }
+  for (int p = 7; n > 1; p += 2)
+    while (n % p == 0) {
+      fac[nf++] = p;
+      n /= p;
+    }
+  return nf;
+}
+
+// pitched host <-> device copies of (nx, rows) Fortran blocks
+static int upload2d(qgcm_hip_ctx *c, double *dst, int ld, const double *src, int nx, long rows) {
+  HIPCHECK(hipMemcpy2DAsync(dst, (size_t)ld * 8, src, (size_t)nx * 8, (size_t)nx * 8, (size_t)rows,
+                            hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+static int download2d(qgcm_hip_ctx *c, double *dst, const double *src, int ld, int nx, long rows) {
+  HIPCHECK(hipMemcpy2DAsync(dst, (size_t)nx * 8, src, (size_t)ld * 8, (size_t)nx * 8, (size_t)rows,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int dalloc(double **p, size_t n) {
+  HIPCHECK(hipMalloc((void **)p, n * sizeof(double)));
+  HIPCHECK(hipMemset(*p, 0, n * sizeof(double)));
+  return 0;
+}
+
+extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, int device) {
+  if (!h || !prm) QG_FAIL("qgcm_hip_create: null argument");
+  *h = nullptr;
+  if (prm->nlo < 2 || prm->nlo > QG_MAXL) QG_FAIL("qgcm_hip_create: nlo=%d outside 2..%d", prm->nlo, QG_MAXL);
+  if (prm->nxpo < 4 || prm->nypo < 4) QG_FAIL("qgcm_hip_create: grid too small");
+  if (prm->cyclic) QG_FAIL("qgcm_hip_create: cyclic ocean not built yet");
+  if (prm->nlo > 4) QG_FAIL("qgcm_hip_create: kernels are instantiated for nlo = 2, 3, 4");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) QG_FAIL("qgcm_hip_create: no HIP device (%s) - there is no CPU fallback", hipGetErrorString(e));
+  if (device >= 0) HIPCHECK(hipSetDevice(device));
+  qgcm_hip_ctx *c = new qgcm_hip_ctx();
+  memset(&c->prm, 0, sizeof(c->prm));
+  c->prm = *prm;
+  HIPCHECK(hipGetDevice(&c->device));
+  QgGeom &g = c->g;
+  g.nx = prm->nxpo; g.ny = prm->nypo; g.nl = prm->nlo; g.cyc = prm->cyclic;
+  g.nxt = g.nx - 1;
+  g.nk = g.cyc ? g.nxt : g.nxt - 1;
+  g.ldx = round_up(g.nx, 16);
+  g.ldw = round_up(g.nxt + 1, 16);
+  g.fstride = (long)g.ldx * g.ny;
+  g.wstride = (long)g.ldw * g.ny;
+  HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const size_t F = (size_t)g.fstride, W = (size_t)g.wstride;
+  for (int i = 0; i < 2; ++i) {
+    if (dalloc(&c->p[i], F * g.nl)) return 1;
+    if (dalloc(&c->q[i], F * g.nl)) return 1;
+  }
+  c->ip = c->iq = 0;
+  if (dalloc(&c->wekpo, F) || dalloc(&c->entoc, F) || dalloc(&c->ddynoc, F)) return 1;
+  if (dalloc(&c->ochom, F * (g.nl - 1))) return 1;
+  if (dalloc(&c->yporel, g.ny)) return 1;
+  if (dalloc(&c->wrk, W * g.nl) || dalloc(&c->bet, W * g.nl) || dalloc(&c->bet_tmp, W)) return 1;
+  if (dalloc(&c->rowsum, (size_t)g.ny * g.nl)) return 1;
+  if (dalloc(&c->pch1, (size_t)g.ny * g.nl) || dalloc(&c->pch2, (size_t)g.ny * g.nl) || dalloc(&c->pbh, g.ny)) return 1;
+  HIPCHECK(hipMalloc((void **)&c->sc, sizeof(QgScalars)));
+  HIPCHECK(hipMemset(c->sc, 0, sizeof(QgScalars)));
+  c->twid = nullptr;
+  c->sintab = nullptr;
+  c->grid_set = c->homog_set = false;
+  c->profiling = false;
+  HIPCHECK(hipEventCreate(&c->ev0));
+  HIPCHECK(hipEventCreate(&c->ev1));
+  memset(&c->cs, 0, sizeof(c->cs));
+  HIPCHECK(hipDeviceSynchronize()); // the zero fills above ran on the null stream
+  *h = c;
+  return 0;
+}
+
+extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
+  if (!c) return 0;
+  hipStreamSynchronize(c->stream);
+  for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+  double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
+                    c->wrk,  c->bet,  c->bet_tmp, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
+  for (double *p : ptrs)
+    if (p) hipFree(p);
+  if (c->twid) hipFree(c->twid);
+  hipFree(c->sc);
+  hipEventDestroy(c->ev0);
+  hipEventDestroy(c->ev1);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+// Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477
+static void build_bet(const QgGeom &g, double aoc, const double *boc /* per spectral index */, double *tab /* ny*ldw */) {
+  for (int k = 0; k < g.nk; ++k) {
+    double betinv = 1.0 / boc[k];
+    tab[(size_t)1 * g.ldw + k] = betinv; // row j=2
+    for (int j = 3; j <= g.ny - 1; ++j) {
+      double gam = aoc * betinv;
+      betinv = 1.0 / (boc[k] - aoc * gam);
+      tab[(size_t)(j - 1) * g.ldw + k] = betinv;
+    }
+  }
+}
+
+extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const double *bd2oc, const double *ddynoc) {
+  if (!c || !yporel || !bd2oc) QG_FAIL("qgcm_hip_set_grid: null argument");
+  const QgGeom &g = c->g;
+  HIPCHECK(hipMemcpy(c->yporel, yporel, sizeof(double) * g.ny, hipMemcpyHostToDevice));
+  if (ddynoc) {
+    if (upload2d(c, c->ddynoc, g.ldx, ddynoc, g.nx, g.ny)) return 1;
+  }
+  c->bd2oc.assign(bd2oc, bd2oc + g.nxt);
+  // pivot tables per mode: boc = bd2oc - rdm2oc(m)   (src/ocisubs.F:148-150)
+  std::vector<double> tab((size_t)g.wstride * g.nl, 0.0), boc(g.nk);
+  for (int m = 0; m < g.nl; ++m) {
+    for (int k = 0; k < g.nk; ++k) boc[k] = bd2oc[k] - c->prm.rdm2oc[m];
+    build_bet(g, c->prm.aoc, boc.data(), tab.data() + (size_t)g.wstride * m);
+  }
+  HIPCHECK(hipMemcpy(c->bet, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  // FFT tables: complex length N = nxto (box DST-I of length nxto-1)
+  const int N = g.nxt;
+  c->fftN = N;
+  c->nfac = factorize(N, c->fac);
+  if (c->nfac > QG_MAXFAC) QG_FAIL("qgcm_hip_set_grid: too many FFT factors");
+  std::vector<double2> tw(N);
+  const double twopi = 6.28318530717958647692528676655900577;
+  for (int t = 0; t < N; ++t) {
+    double ang = -twopi * (double)t / (double)N;
+    tw[t].x = cos(ang);
+    tw[t].y = sin(ang);
+  }
+  std::vector<double> st(N / 2 + 2);
+  const double pi = 3.14159265358979323846264338327950288;
+  for (int k = 0; k <= N / 2 + 1; ++k) st[k] = 2.0 * sin((double)k * (pi / (double)N)); // dsinti.f:20-24
+  if (c->twid) hipFree(c->twid);
+  if (c->sintab) hipFree(c->sintab);
+  HIPCHECK(hipMalloc((void **)&c->twid, sizeof(double2) * N));
+  HIPCHECK(hipMalloc((void **)&c->sintab, sizeof(double) * st.size()));
+  HIPCHECK(hipMemcpy(c->twid, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(c->sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
+  c->dst_lds = (size_t)2 * N * sizeof(cplx) + 2 * DST_NT * sizeof(double);
+  if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
+  HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
+  HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
+  const int nr = g.ny - 2;
+  if ((nr + TH_NC - 1) / TH_NC > 32) QG_FAIL("qgcm_hip_set_grid: nypo=%d exceeds the single-segment Thomas kernel (<= 2050)", g.ny);
+  c->grid_set = true;
+  return 0;
+}
+
+static int lu_factor(int n, double *a, int *piv) {
+  for (int k = 0; k < n; ++k) {
+    int p = k;
+    double mx = fabs(a[k + n * k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(a[i + n * k]) > mx) {
+        mx = fabs(a[i + n * k]);
+        p = i;
+      }
+    piv[k] = p;
+    if (mx == 0.0) return k + 1;
+    if (p != k)
+      for (int j = 0; j < n; ++j) {
+        double t = a[k + n * j];
+        a[k + n * j] = a[p + n * j];
+        a[p + n * j] = t;
+      }
+    for (int i = k + 1; i < n; ++i) {
+      a[i + n * k] /= a[k + n * k];
+      for (int j = k + 1; j < n; ++j) a[i + n * j] -= a[i + n * k] * a[k + n * j];
+    }
+  }
+  return 0;
+}
+
+extern "C" int qgcm_hip_set_homog_box(qgcm_hip_handle c, const double *ochom, const double *cdiffo, const double *cdhoc) {
+  if (!c || !ochom || !cdiffo || !cdhoc) QG_FAIL("qgcm_hip_set_homog_box: null argument");
+  if (c->g.cyc) QG_FAIL("qgcm_hip_set_homog_box: handle is cyclic");
+  const QgGeom &g = c->g;
+  const int nl = g.nl, n1 = nl - 1;
+  if (upload2d(c, c->ochom, g.ldx, ochom, g.nx, (long)g.ny * n1)) return 1;
+  memcpy(c->cs.cdiffo, cdiffo, sizeof(double) * nl * n1);
+  memcpy(c->cs.cdhoc, cdhoc, sizeof(double) * n1 * n1);
+  memcpy(c->cs.cdhlu, cdhoc, sizeof(double) * n1 * n1);
+  int info = lu_factor(n1, c->cs.cdhlu, c->cs.ipiv); // DGETRF, src/conhoms.F:627
+  if (info) QG_FAIL("qgcm_hip_set_homog_box: cdhoc is singular (info=%d)", info);
+  c->homog_set = true;
+  return 0;
+}
+
+extern "C" int qgcm_hip_set_homog_cyc(qgcm_hip_handle c, const double *, const double *, const double *, const double *,
+                                      const double *, const double *, const double *, const double *, double, double) {
+  (void)c;
+  QG_FAIL("qgcm_hip_set_homog_cyc: cyclic ocean not built yet");
+}
+
+extern "C" int qgcm_hip_set_state(qgcm_hip_handle c, const double *po, const double *pom, const double *qo, const double *qom) {
+  if (!c) QG_FAIL("qgcm_hip_set_state: null handle");
+  const QgGeom &g = c->g;
+  const long rows = (long)g.ny * g.nl;
+  if (po && upload2d(c, c->p[c->ip], g.ldx, po, g.nx, rows)) return 1;
+  if (pom && upload2d(c, c->p[c->ip ^ 1], g.ldx, pom, g.nx, rows)) return 1;
+  if (qo && upload2d(c, c->q[c->iq], g.ldx, qo, g.nx, rows)) return 1;
+  if (qom && upload2d(c, c->q[c->iq ^ 1], g.ldx, qom, g.nx, rows)) return 1;
+  return 0;
+}
+
+extern "C" int qgcm_hip_get_state(qgcm_hip_handle c, double *po, double *pom, double *qo, double *qom) {
+  if (!c) QG_FAIL("qgcm_hip_get_state: null handle");
+  const QgGeom &g = c->g;
+  const long rows = (long)g.ny * g.nl;
+  if (po && download2d(c, po, c->p[c->ip], g.ldx, g.nx, rows)) return 1;
+  if (pom && download2d(c, pom, c->p[c->ip ^ 1], g.ldx, g.nx, rows)) return 1;
+  if (qo && download2d(c, qo, c->q[c->iq], g.ldx, g.nx, rows)) return 1;
+  if (qom && download2d(c, qom, c->q[c->iq ^ 1], g.ldx, g.nx, rows)) return 1;
+  return 0;
+}
+
+extern "C" int qgcm_hip_set_forcing(qgcm_hip_handle c, const double *wekpo, const double *entoc, const double *xon) {
+  if (!c) QG_FAIL("qgcm_hip_set_forcing: null handle");
+  const QgGeom &g = c->g;
+  if (wekpo && upload2d(c, c->wekpo, g.ldx, wekpo, g.nx, g.ny)) return 1;
+  if (entoc && upload2d(c, c->entoc, g.ldx, entoc, g.nx, g.ny)) return 1;
+  if (xon) {
+    HIPCHECK(hipMemcpyAsync((char *)c->sc + offsetof(QgScalars, xon), xon, sizeof(double) * (g.nl - 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+extern "C" int qgcm_hip_set_cyc_forcing(qgcm_hip_handle c, double, double, const double *, const double *) {
+  (void)c;
+  QG_FAIL("qgcm_hip_set_cyc_forcing: cyclic ocean not built yet");
+}
+
+extern "C" int qgcm_hip_set_scalars(qgcm_hip_handle c, const double *s) {
+  if (!c || !s) QG_FAIL("qgcm_hip_set_scalars: null argument");
+  const int nl = c->g.nl, o = 2 * (nl - 1);
+  QgScalars h;
+  HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < nl - 1; ++k) {
+    h.dpioc[k] = s[k];
+    h.dpiocp[k] = s[nl - 1 + k];
+  }
+  for (int k = 0; k < nl; ++k) {
+    h.ocncs[k] = s[o + k];
+    h.ocncn[k] = s[o + nl + k];
+    h.ocncsp[k] = s[o + 2 * nl + k];
+    h.ocncnp[k] = s[o + 3 * nl + k];
+  }
+  HIPCHECK(hipMemcpyAsync(c->sc, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int qgcm_hip_get_scalars(qgcm_hip_handle c, double *s) {
+  if (!c || !s) QG_FAIL("qgcm_hip_get_scalars: null argument");
+  const int nl = c->g.nl, o = 2 * (nl - 1);
+  QgScalars h;
+  HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < nl - 1; ++k) {
+    s[k] = h.dpioc[k];
+    s[nl - 1 + k] = h.dpiocp[k];
+  }
+  for (int k = 0; k < nl; ++k) {
+    s[o + k] = c->g.cyc ? h.ocncs[k] : 0.0;
+    s[o + nl + k] = c->g.cyc ? h.ocncn[k] : 0.0;
+    s[o + 2 * nl + k] = c->g.cyc ? h.ocncsp[k] : 0.0;
+    s[o + 3 * nl + k] = c->g.cyc ? h.ocncnp[k] : 0.0;
+  }
+  return 0;
+}
+
+extern "C" int qgcm_hip_get_inv_diag(qgcm_hip_handle c, double *xinhom, double *coef) {
+  if (!c) QG_FAIL("qgcm_hip_get_inv_diag: null handle");
+  const int nl = c->g.nl;
+  QgScalars h;
+  HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (xinhom)
+    for (int m = 0; m < nl; ++m) xinhom[m] = h.xinhom[m];
+  if (coef) {
+    if (c->g.cyc) {
+      for (int m = 0; m < nl - 1; ++m) {
+        coef[m] = h.c1[m];
+        coef[nl - 1 + m] = h.c2[m];
+      }
+      coef[2 * (nl - 1)] = h.c3;
+    } else {
+      for (int m = 0; m < nl - 1; ++m) coef[m] = h.hclco[m];
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// kernel launches
+// ---------------------------------------------------------------------------
+struct KTimer {
+  qgcm_hip_ctx *c;
+  int id;
+  KTimer(qgcm_hip_ctx *c_, int id_) : c(c_), id(id_) {
+    if (c->profiling) hipEventRecord(c->ev0, c->stream);
+  }
+  ~KTimer() {
+    if (c->profiling) {
+      hipEventRecord(c->ev1, c->stream);
+      hipEventSynchronize(c->ev1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      c->kms[id] += ms;
+      c->klaunch[id] += 1;
+    }
+  }
+};
+
+static int launch_tend(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  const qgcm_hip_params &pr = c->prm;
+  QgTendParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.pom = c->p[c->ip ^ 1];
+  P.po = c->p[c->ip];
+  P.qo = c->q[c->iq];
+  P.qnew = c->q[c->iq ^ 1];
+  P.wekpo = c->wekpo; P.entoc = c->entoc; P.ddynoc = c->ddynoc; P.yporel = c->yporel;
+  P.wrk = c->wrk; P.sc = c->sc; P.bsum = nullptr;
+  // scalar prologue of qgostep, src/qgosubs.F:76-82, and ocadif, :276-277
+  P.adfaco = 1.0 / (12.0 * pr.dxo * pr.dyo * pr.fnot);
+  P.dxom2 = 1.0 / (pr.dxo * pr.dxo);
+  P.bcfaco = pr.bccooc * P.dxom2 / (0.5 * pr.bccooc + 1.0);
+  P.tdto = pr.tdto;
+  P.bdrfac = 0.5 * (pr.fnot >= 0.0 ? 1.0 : -1.0) * pr.delek / pr.hoc[g.nl - 1];
+  P.fnot = pr.fnot; P.beta = pr.beta;
+  for (int k = 0; k < g.nl; ++k) {
+    P.fohfac[k] = pr.fnot / pr.hoc[k];
+    P.ah2fac[k] = pr.ah2oc[k] / pr.fnot;
+    P.ah4fac[k] = pr.ah4oc[k] / pr.fnot;
+  }
+  for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
+  dim3 grid((g.nx + TEND_TX - 1) / TEND_TX, (g.ny + TEND_TY - 1) / TEND_TY);
+  KTimer t(c, KN_TEND);
+  switch (g.nl) {
+    case 2: hipLaunchKernelGGL((k_tend<2, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
+    case 3: hipLaunchKernelGGL((k_tend<3, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL((k_tend<4, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
+    default: QG_FAIL("k_tend: unsupported nlo");
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse) {
+  const QgGeom &g = c->g;
+  QgDstParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.wrk = wrk;
+  P.twid = c->twid;
+  P.sintab = c->sintab;
+  P.rowsum = inverse ? c->rowsum : nullptr;
+  P.N = c->fftN;
+  P.nfac = c->nfac;
+  for (int f = 0; f < c->nfac; ++f) P.fac[f] = c->fac[f];
+  P.nlayers = nlayers;
+  const int nrows = g.ny - 2;
+  dim3 grid((nrows + 1) / 2, nlayers);
+  KTimer t(c, inverse ? KN_DSTI : KN_DSTF);
+  if (inverse) hipLaunchKernelGGL((k_dst_box<true>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
+  else hipLaunchKernelGGL((k_dst_box<false>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *bet, int nlayers) {
+  const QgGeom &g = c->g;
+  QgThomasParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.wrk = wrk;
+  P.bet = bet;
+  P.aoc = c->prm.aoc;
+  P.ftnorm = g.cyc ? 1.0 / g.nxt : 0.5 / g.nxt; // src/ocisubs.F:440, 547
+  P.nlayers = nlayers;
+  const int nr = g.ny - 2;
+  const int need = (nr + TH_NC - 1) / TH_NC;
+  dim3 grid((g.nk + TH_KW - 1) / TH_KW, nlayers);
+  KTimer t(c, KN_THOMAS);
+  if (need <= 1) hipLaunchKernelGGL((k_thomas<1>), grid, dim3(TH_NT), 0, c->stream, P);
+  else if (need <= 2) hipLaunchKernelGGL((k_thomas<2>), grid, dim3(TH_NT), 0, c->stream, P);
+  else if (need <= 4) hipLaunchKernelGGL((k_thomas<4>), grid, dim3(TH_NT), 0, c->stream, P);
+  else if (need <= 8) hipLaunchKernelGGL((k_thomas<8>), grid, dim3(TH_NT), 0, c->stream, P);
+  else if (need <= 16) hipLaunchKernelGGL((k_thomas<16>), grid, dim3(TH_NT), 0, c->stream, P);
+  else if (need <= 32) hipLaunchKernelGGL((k_thomas<32>), grid, dim3(TH_NT), 0, c->stream, P);
+  else QG_FAIL("k_thomas: nypo too large for the single-segment kernel");
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_constr(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  const qgcm_hip_params &pr = c->prm;
+  QgConstrParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.rowsum = c->rowsum;
+  P.wrk = c->wrk;
+  P.sc = c->sc;
+  P.cs = c->cs;
+  P.dxo = pr.dxo; P.dyo = pr.dyo; P.tdto = pr.tdto; P.fnot = pr.fnot;
+  for (int k = 0; k < g.nl; ++k) {
+    P.gpoc[k] = pr.gpoc[k];
+    P.hoc[k] = pr.hoc[k];
+  }
+  for (int i = 0; i < g.nl * g.nl; ++i) {
+    P.ctl2m[i] = pr.ctl2moc[i];
+    P.ctm2l[i] = pr.ctm2loc[i];
+  }
+  KTimer t(c, KN_CONSTR);
+  hipLaunchKernelGGL(k_constr_box, dim3(1), dim3(CS_NT), 0, c->stream, P);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_unpack(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  QgUnpackParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.wrk = c->wrk;
+  P.ochom = c->ochom;
+  P.pnew = c->p[c->ip ^ 1];
+  P.sc = c->sc;
+  P.pch1 = c->pch1; P.pch2 = c->pch2; P.pbh = c->pbh;
+  for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  dim3 grid((g.nx + 255) / 256, g.ny);
+  KTimer t(c, KN_UNPACK);
+  switch (g.nl) {
+    case 2: hipLaunchKernelGGL((k_unpack_box<2>), grid, dim3(256), 0, c->stream, P); break;
+    case 3: hipLaunchKernelGGL((k_unpack_box<3>), grid, dim3(256), 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL((k_unpack_box<4>), grid, dim3(256), 0, c->stream, P); break;
+    default: QG_FAIL("k_unpack: unsupported nlo");
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_ocqbdy(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  const qgcm_hip_params &pr = c->prm;
+  QgBdyParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.po = c->p[c->ip];
+  P.qo = c->q[c->iq];
+  P.ddynoc = c->ddynoc;
+  P.yporel = c->yporel;
+  const double dxom2 = 1.0 / (pr.dxo * pr.dxo);
+  P.bcfaco_f0 = pr.bccooc * dxom2 / (0.5 * pr.bccooc + 1.0) / pr.fnot; // src/vorsubs.F:268
+  P.beta = pr.beta;
+  for (int k = 0; k < g.nl; ++k)
+    for (int l = 0; l < g.nl; ++l) P.f0A[k + g.nl * l] = pr.fnot * pr.amatoc[k + g.nl * l];
+  const int nmax = g.nx > g.ny ? g.nx : g.ny;
+  dim3 grid((nmax + 255) / 256, g.cyc ? 2 : 4, g.nl);
+  KTimer t(c, KN_OCQBDY);
+  hipLaunchKernelGGL(k_ocqbdy, grid, dim3(256), 0, c->stream, P);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_lfavg(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  const long n = g.fstride * g.nl;
+  KTimer t(c, KN_LFAVG);
+  hipLaunchKernelGGL(k_lf_average, dim3(2048), dim3(256), 0, c->stream, c->q[c->iq], c->q[c->iq ^ 1], c->p[c->ip],
+                     c->p[c->ip ^ 1], n, c->sc, g.nl, g.cyc);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static int check_ready(qgcm_hip_ctx *c, const char *who) {
+  if (!c) QG_FAIL("%s: null handle", who);
+  if (!c->grid_set) QG_FAIL("%s: qgcm_hip_set_grid has not been called", who);
+  return 0;
+}
+
+extern "C" int qgcm_hip_qgostep(qgcm_hip_handle c) {
+  if (check_ready(c, "qgcm_hip_qgostep")) return 1;
+  if (launch_tend(c)) return 1;
+  c->iq ^= 1; // the old qom buffer now holds qo; the old qo is qom
+  return 0;
+}
+
+extern "C" int qgcm_hip_ocinvq(qgcm_hip_handle c) {
+  if (check_ready(c, "qgcm_hip_ocinvq")) return 1;
+  if (!c->homog_set) QG_FAIL("qgcm_hip_ocinvq: homogeneous solutions not set");
+  if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
+  if (launch_thomas(c, c->wrk, c->bet, c->g.nl)) return 1;
+  if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
+  if (launch_constr(c)) return 1;
+  if (launch_unpack(c)) return 1;
+  c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
+  return 0;
+}
+
+extern "C" int qgcm_hip_ocqbdy(qgcm_hip_handle c) {
+  if (check_ready(c, "qgcm_hip_ocqbdy")) return 1;
+  return launch_ocqbdy(c);
+}
+
+extern "C" int qgcm_hip_lf_average(qgcm_hip_handle c) {
+  if (check_ready(c, "qgcm_hip_lf_average")) return 1;
+  return launch_lfavg(c);
+}
+
+static int one_step(qgcm_hip_ctx *c, int s) {
+  if (qgcm_hip_qgostep(c)) return 1;
+  if (qgcm_hip_ocinvq(c)) return 1;
+  if (qgcm_hip_ocqbdy(c)) return 1;
+  if ((s - 1) % 25 == 0)
+    if (qgcm_hip_lf_average(c)) return 1;
+  return 0;
+}
+
+static int get_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
+  const int phase = (s0 - 1) % 25;
+  const int key = (c->ip << 16) | (c->iq << 8) | phase;
+  auto it = c->graphs.find(key);
+  if (it != c->graphs.end()) {
+    *out = it->second;
+    return 0;
+  }
+  hipGraph_t graph;
+  const int ip0 = c->ip, iq0 = c->iq;
+  HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int s = s0; s < s0 + kGraphBlock && !rc; ++s) rc = one_step(c, s);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  c->ip = ip0; // capture does not execute: restore the rotation state
+  c->iq = iq0;
+  if (rc) return 1;
+  HIPCHECK(e);
+  hipGraphExec_t exec;
+  HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  HIPCHECK(hipGraphDestroy(graph));
+  c->graphs[key] = exec;
+  *out = exec;
+  return 0;
+}
+
+extern "C" int qgcm_hip_steps(qgcm_hip_handle c, int s0, int n) {
+  if (check_ready(c, "qgcm_hip_steps")) return 1;
+  if (s0 < 1 || n < 0) QG_FAIL("qgcm_hip_steps: bad step range");
+  int s = s0;
+  while (n >= kGraphBlock && !c->profiling) {
+    hipGraphExec_t ge;
+    if (get_graph(c, s, &ge)) return 1;
+    HIPCHECK(hipGraphLaunch(ge, c->stream));
+    s += kGraphBlock; // 50 steps: both rotations are back where they started
+    n -= kGraphBlock;
+  }
+  for (; n > 0; --n, ++s)
+    if (one_step(c, s)) return 1;
+  return 0;
+}
+
+extern "C" int qgcm_hip_sync(qgcm_hip_handle c) {
+  if (!c) QG_FAIL("qgcm_hip_sync: null handle");
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *boc) {
+  if (check_ready(c, "qgcm_hip_helmholtz")) return 1;
+  if (!wrk || !boc) QG_FAIL("qgcm_hip_helmholtz: null argument");
+  const QgGeom &g = c->g;
+  // pivots for this boc (box: boc(i-1) multiplies sine wavenumber i-1, src/ocisubs.F:470-478)
+  std::vector<double> tab((size_t)g.wstride, 0.0);
+  build_bet(g, c->prm.aoc, boc, tab.data());
+  HIPCHECK(hipMemcpyAsync(c->bet_tmp, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // interior columns i=2..nx-1 of every row -> wrk(c = i-2, j)
+  HIPCHECK(hipMemcpy2DAsync(c->wrk, (size_t)g.ldw * 8, wrk + 1, (size_t)g.nx * 8, (size_t)(g.nx - 2) * 8, (size_t)g.ny,
+                            hipMemcpyHostToDevice, c->stream));
+  if (launch_dst(c, c->wrk, 1, false)) return 1;
+  if (launch_thomas(c, c->wrk, c->bet_tmp, 1)) return 1;
+  if (launch_dst(c, c->wrk, 1, true)) return 1;
+  HIPCHECK(hipMemcpy2DAsync(wrk + 1, (size_t)g.nx * 8, c->wrk, (size_t)g.ldw * 8, (size_t)(g.nx - 2) * 8, (size_t)g.ny,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  // solid-boundary values are zero (src/ocisubs.F:496-509)
+  for (int j = 0; j < g.ny; ++j) {
+    wrk[(size_t)j * g.nx] = 0.0;
+    wrk[(size_t)j * g.nx + g.nx - 1] = 0.0;
+  }
+  for (int i = 0; i < g.nx; ++i) {
+    wrk[i] = 0.0;
+    wrk[(size_t)(g.ny - 1) * g.nx + i] = 0.0;
+  }
+  return 0;
+}
+
+extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) {
+  if (check_ready(c, "qgcm_hip_time_steps")) return 1;
+  hipEvent_t a, b;
+  HIPCHECK(hipEventCreate(&a));
+  HIPCHECK(hipEventCreate(&b));
+  // instantiate any graph needed outside the timed region
+  if (n >= kGraphBlock) {
+    hipGraphExec_t ge;
+    if (get_graph(c, s0, &ge)) return 1;
+  }
+  HIPCHECK(hipEventRecord(a, c->stream));
+  if (qgcm_hip_steps(c, s0, n)) return 1;
+  HIPCHECK(hipEventRecord(b, c->stream));
+  HIPCHECK(hipEventSynchronize(b));
+  float t = 0.f;
+  HIPCHECK(hipEventElapsedTime(&t, a, b));
+  if (ms) *ms = t;
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return 0;
+}
+
+extern "C" int qgcm_hip_profile_steps(qgcm_hip_handle c, int s0, int n, double *ms, int *launches, const char **names, int *nk) {
+  if (check_ready(c, "qgcm_hip_profile_steps")) return 1;
+  if (!nk || *nk < KN_COUNT) QG_FAIL("qgcm_hip_profile_steps: need room for %d kernels", KN_COUNT);
+  for (int i = 0; i < KN_COUNT; ++i) {
+    c->kms[i] = 0.0;
+    c->klaunch[i] = 0;
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  c->profiling = true;
+  int rc = qgcm_hip_steps(c, s0, n);
+  c->profiling = false;
+  if (rc) return 1;
+  for (int i = 0; i < KN_COUNT; ++i) {
+    if (ms) ms[i] = c->kms[i];
+    if (launches) launches[i] = c->klaunch[i];
+    if (names) names[i] = kKernelNames[i];
+  }
+  *nk = KN_COUNT;
+  return 0;
+}
+
+extern "C" int qgcm_hip_copy_bandwidth(qgcm_hip_handle c, size_t bytes, int reps, double *gbps) {
+  if (!c || !gbps) QG_FAIL("qgcm_hip_copy_bandwidth: null argument");
+  double2 *a = nullptr, *b = nullptr;
+  const long n = (long)(bytes / sizeof(double2));
+  HIPCHECK(hipMalloc((void **)&a, n * sizeof(double2)));
+  HIPCHECK(hipMalloc((void **)&b, n * sizeof(double2)));
+  HIPCHECK(hipMemset(a, 1, n * sizeof(double2)));
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, c->stream, a, b, n);
+  HIPCHECK(hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, c->stream, a, b, n);
+  HIPCHECK(hipEventRecord(e1, c->stream));
+  HIPCHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+  *gbps = 2.0 * (double)n * sizeof(double2) * reps / (ms * 1e-3) / 1e9;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(a);
+  hipFree(b);
+  return 0;
+}
+
+extern "C" void *qgcm_hip_stream(qgcm_hip_handle c) { return c ? (void *)c->stream : nullptr; }

@@ -1,0 +1,113 @@
+"""Grid + physical parameters of one ocean configuration.
+
+Mirrors what the reference takes from MODULE parameters (compile-time,
+src/parameters_data.F:23-147) and from input.params (run-time, order fixed by
+src/in_param.f:31-142); only the entries the ocean hot path reads are kept.
+"""
+from dataclasses import dataclass, field
+from typing import Tuple
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class OceanConfig:
+    name: str
+    nxta: int
+    nyta: int
+    nxaooc: int
+    nyaooc: int
+    ndxr: int
+    nlo: int
+    fnot: float
+    beta: float
+    cyclic: bool
+    dxo: float
+    dta: float = 180.0
+    nstr: int = 3
+    delek: float = 2.0
+    bccooc: float = 0.2
+    ah2oc: Tuple[float, ...] = (0.0, 0.0, 0.0)
+    ah4oc: Tuple[float, ...] = (2.0e9, 2.0e9, 2.0e9)
+    hoc: Tuple[float, ...] = (350.0, 750.0, 2900.0)
+    gpoc: Tuple[float, ...] = (0.015, 0.0075)
+
+    # derived grid parameters, src/parameters_data.F (nxto = ndxr*nxaooc, ...)
+    @property
+    def nxto(self):
+        return self.ndxr * self.nxaooc
+
+    @property
+    def nyto(self):
+        return self.ndxr * self.nyaooc
+
+    @property
+    def nxpo(self):
+        return self.nxto + 1
+
+    @property
+    def nypo(self):
+        return self.nyto + 1
+
+    @property
+    def dto(self):  # src/q-gcm.F:381
+        return self.nstr * self.dta
+
+    @property
+    def tdto(self):  # src/q-gcm.F:440
+        return 2.0 * self.dto
+
+    @property
+    def dyo(self):  # src/q-gcm.F:413
+        return self.dxo
+
+    @property
+    def xlo(self):
+        return self.nxto * self.dxo
+
+    @property
+    def ylo(self):
+        return self.nyto * self.dyo
+
+    def yporel(self):
+        """src/q-gcm.F:380-427 - depends on the *atmosphere* dims even ocean-only."""
+        dxa = self.ndxr * self.dxo
+        dya = dxa
+        yla = self.nyta * dya
+        ny1 = 1 + (self.nyta - self.nyaooc) // 2
+        ypo = (ny1 - 1) * dya + np.arange(self.nypo, dtype=np.float64) * self.dyo
+        return ypo - 0.5 * yla
+
+    def model_years_per_day(self, steps_per_s):
+        """steps/s * dto / 365  (secsyr = 86400*365, src/timinfo_data.F:33-35)."""
+        return steps_per_s * self.dto / 365.0
+
+
+_NATL = dict(fnot=9.37456e-05, beta=1.75360e-11, cyclic=False)
+_SOCN = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True)
+
+PRESETS = {
+    # parity-test grids (same dimension sets as oracle/ref_binding.CONFIGS)
+    "box_tiny": OceanConfig("box_tiny", 8, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
+                            ah4oc=(3.2e12,) * 3, **_NATL),
+    "box_small": OceanConfig("box_small", 12, 10, 6, 5, 16, 3, dxo=5.0e4, dta=360.0,
+                             ah4oc=(2.0e11,) * 3, **_NATL),
+    "box_tiny2": OceanConfig("box_tiny2", 8, 8, 5, 4, 6, 2, fnot=5.92e-05, beta=2.08e-11, cyclic=False,
+                             dxo=1.0e5, dta=720.0, ah2oc=(0.0, 0.0), ah4oc=(3.2e12, 3.2e12),
+                             hoc=(500.0, 3500.0), gpoc=(0.02,)),
+    "cyc_tiny": OceanConfig("cyc_tiny", 4, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
+                            ah4oc=(3.2e12,) * 3, **_SOCN),
+    "cyc_small": OceanConfig("cyc_small", 6, 10, 6, 4, 16, 3, dxo=5.0e4, dta=360.0,
+                             ah4oc=(2.0e11,) * 3, **_SOCN),
+    # examples/double_gyre_ocean_only: parameters_data.F.dg_oo + input.params.dg_oo (BASELINE configs[0], [1])
+    "natl5": OceanConfig("natl5", 384, 96, 60, 60, 16, 3, dxo=5.0e3, **_NATL),
+    # examples/southern_ocean_ocean_only (BASELINE configs[2])
+    "socn5": OceanConfig("socn5", 288, 108, 288, 36, 16, 3, dxo=5.0e3, **_SOCN),
+    # src/parameters_data.F.NAtl.1km + src/input.params.NAtl.1km with dta=60,nstr=3 (SURVEY 8d caveat)
+    "natl1": OceanConfig("natl1", 384, 96, 60, 60, 80, 3, dxo=1.0e3, dta=60.0, bccooc=0.1,
+                         ah4oc=(5.0e7,) * 3, **_NATL),
+}
+
+
+def preset(name):
+    return PRESETS[name]

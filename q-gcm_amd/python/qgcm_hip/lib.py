@@ -1,0 +1,86 @@
+"""ctypes binding of the C ABI declared in include/qgcm_hip.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAXL = 8
+
+
+class QgcmHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.normpath(os.path.join(HERE, "..", "..", "lib", "libqgcm_hip.so"))
+
+
+class Params(C.Structure):
+    """struct qgcm_hip_params (include/qgcm_hip.h)."""
+    _fields_ = [
+        ("nxpo", C.c_int), ("nypo", C.c_int), ("nlo", C.c_int), ("cyclic", C.c_int),
+        ("fnot", C.c_double), ("beta", C.c_double), ("dxo", C.c_double), ("dyo", C.c_double),
+        ("tdto", C.c_double), ("delek", C.c_double), ("bccooc", C.c_double),
+        ("ah2oc", C.c_double * MAXL), ("ah4oc", C.c_double * MAXL),
+        ("hoc", C.c_double * MAXL), ("gpoc", C.c_double * MAXL),
+        ("amatoc", C.c_double * (MAXL * MAXL)), ("ctl2moc", C.c_double * (MAXL * MAXL)),
+        ("ctm2loc", C.c_double * (MAXL * MAXL)), ("rdm2oc", C.c_double * MAXL),
+        ("aoc", C.c_double),
+    ]
+
+
+# every symbol include/qgcm_hip.h declares
+SYMBOLS = [
+    "qgcm_hip_create", "qgcm_hip_destroy", "qgcm_hip_last_error", "qgcm_hip_abi_version",
+    "qgcm_hip_set_grid", "qgcm_hip_set_homog_box", "qgcm_hip_set_homog_cyc",
+    "qgcm_hip_set_state", "qgcm_hip_get_state", "qgcm_hip_set_forcing", "qgcm_hip_set_cyc_forcing",
+    "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag",
+    "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average",
+    "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
+    "qgcm_hip_time_steps", "qgcm_hip_profile_steps", "qgcm_hip_copy_bandwidth", "qgcm_hip_stream",
+]
+
+_lib = None
+
+
+def load_library():
+    """Load libqgcm_hip.so; raises QgcmHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise QgcmHipError("HIP library %s is missing - run __graft_entry__.build() "
+                           "(make -C q-gcm_amd/csrc); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.qgcm_hip_last_error.restype = C.c_char_p
+    L.qgcm_hip_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
+    L.qgcm_hip_destroy.argtypes = [vp]
+    L.qgcm_hip_set_grid.argtypes = [vp, dp, dp, dp]
+    L.qgcm_hip_set_homog_box.argtypes = [vp, dp, dp, dp]
+    L.qgcm_hip_set_homog_cyc.argtypes = [vp] + [dp] * 8 + [C.c_double, C.c_double]
+    L.qgcm_hip_set_state.argtypes = [vp, dp, dp, dp, dp]
+    L.qgcm_hip_get_state.argtypes = [vp, dp, dp, dp, dp]
+    L.qgcm_hip_set_forcing.argtypes = [vp, dp, dp, dp]
+    L.qgcm_hip_set_cyc_forcing.argtypes = [vp, C.c_double, C.c_double, dp, dp]
+    L.qgcm_hip_set_scalars.argtypes = [vp, dp]
+    L.qgcm_hip_get_scalars.argtypes = [vp, dp]
+    L.qgcm_hip_get_inv_diag.argtypes = [vp, dp, dp]
+    for n in ("qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_sync"):
+        getattr(L, n).argtypes = [vp]
+    L.qgcm_hip_steps.argtypes = [vp, C.c_int, C.c_int]
+    L.qgcm_hip_helmholtz.argtypes = [vp, dp, dp]
+    L.qgcm_hip_time_steps.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.qgcm_hip_profile_steps.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+    L.qgcm_hip_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
+    L.qgcm_hip_stream.argtypes = [vp]
+    L.qgcm_hip_stream.restype = vp
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise QgcmHipError(load_library().qgcm_hip_last_error().decode())

@@ -1,0 +1,212 @@
+"""OceanModel - Python mirror of the reference's operator interface for the ocean
+hot path.  The reference exposes three argument-less module procedures acting on
+MODULE ocstate / ochomog arrays (src/q-gcm.F:1243-1249):
+
+    call qgostep ; call ocinvq ; call ocqbdy (qo, po)
+
+Here the same three names are methods, the module arrays are device resident,
+and ``po / pom / qo / qom`` are fetched on demand (properties).  Everything that
+computes goes through the C ABI of include/qgcm_hip.h; nothing here falls back
+to numpy for the per-step path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hostinit
+from .lib import MAXL, Params, QgcmHipError, check, load_library
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    return None if a is None else np.asfortranarray(a, dtype=np.float64)
+
+
+class OceanModel:
+    """One ocean configuration on one MI355X.
+
+    Start-up follows src/q-gcm.F:380-976 for the ocean: grid, eigmod, tridiagonal
+    coefficients, homsol (its Helmholtz solves run on the GPU through
+    qgcm_hip_helmholtz).  A caller that already has the reference's constants
+    (the Fortran host) can pass them in ``consts`` to skip that arithmetic.
+    """
+
+    def __init__(self, cfg, ddynoc=None, device=-1, consts=None):
+        self.cfg = cfg
+        self.L = load_library()
+        self.h = C.c_void_p()
+        nl = cfg.nlo
+        if nl > MAXL:
+            raise QgcmHipError("nlo=%d exceeds QGCM_HIP_MAXL" % nl)
+        self.yporel = cfg.yporel()
+        self.ddynoc = np.zeros((cfg.nxpo, cfg.nypo), order="F") if ddynoc is None else _f(ddynoc)
+        if consts is None:
+            A, rdm2, cl2m, cm2l = hostinit.eigmod(cfg.gpoc, cfg.hoc, cfg.fnot)
+        else:
+            A, rdm2, cl2m, cm2l = (consts[k] for k in ("amatoc", "rdm2oc", "ctl2moc", "ctm2loc"))
+        self.amatoc, self.rdm2oc, self.ctl2moc, self.ctm2loc = A, rdm2, cl2m, cm2l
+        self.aoc, self.bd2oc = hostinit.bd2oc(cfg)
+        p = Params()
+        p.nxpo, p.nypo, p.nlo, p.cyclic = cfg.nxpo, cfg.nypo, nl, int(cfg.cyclic)
+        p.fnot, p.beta, p.dxo, p.dyo = cfg.fnot, cfg.beta, cfg.dxo, cfg.dyo
+        p.tdto, p.delek, p.bccooc, p.aoc = cfg.tdto, cfg.delek, cfg.bccooc, self.aoc
+        for k in range(nl):
+            p.ah2oc[k], p.ah4oc[k], p.hoc[k], p.rdm2oc[k] = cfg.ah2oc[k], cfg.ah4oc[k], cfg.hoc[k], rdm2[k]
+        for k in range(nl - 1):
+            p.gpoc[k] = cfg.gpoc[k]
+        for name, M in (("amatoc", A), ("ctl2moc", cl2m), ("ctm2loc", cm2l)):
+            flat = np.asarray(M).ravel(order="F")
+            arr = getattr(p, name)
+            for i, v in enumerate(flat):
+                arr[i] = v
+        self.params = p
+        check(self.L.qgcm_hip_create(C.byref(self.h), C.byref(p), int(device)))
+        check(self.L.qgcm_hip_set_grid(self.h, _dp(self.yporel), _dp(self.bd2oc), _dp(self.ddynoc)))
+        # homsol
+        if consts is not None and ("ochom" in consts or "pch1oc" in consts):
+            self.homog = consts
+        elif cfg.cyclic:
+            self.homog = hostinit.homsol_cyc(cfg, rdm2, self.bd2oc, self.yporel, self.helmholtz)
+        else:
+            self.homog = hostinit.homsol_box(cfg, rdm2, cm2l, self.bd2oc, self.helmholtz)
+        hg = self.homog
+        if cfg.cyclic:
+            args = [_f(hg["pch1oc"]), _f(hg["pch2oc"]), np.ascontiguousarray(hg["pbhoc"]),
+                    *[np.ascontiguousarray(hg[k], dtype=np.float64) for k in ("aipcho", "hc1soc", "hc2soc", "hc1noc", "hc2noc")]]
+            self._keep = args
+            check(self.L.qgcm_hip_set_homog_cyc(self.h, *[_dp(a) for a in args], float(hg["hbsioc"]), float(hg["aipbho"])))
+        else:
+            args = [_f(hg["ochom"]), _f(hg["cdiffo"]), _f(hg["cdhoc"])]
+            check(self.L.qgcm_hip_set_homog_box(self.h, *[_dp(a) for a in args]))
+        self.nscal = 2 * (nl - 1) + 4 * nl
+        self.step_index = 1  # next 1-based ocean step
+
+    # -- life cycle ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.qgcm_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _f3(self):
+        c = self.cfg
+        return np.zeros((c.nxpo, c.nypo, c.nlo), order="F")
+
+    # -- state ----------------------------------------------------------------
+    def set_p(self, po, pom=None):
+        """Load pressures and derive q and the constraint scalars as the reference
+        does at start-up (src/q-gcm.F:711-731: constr, qcomp, ocqbdy, merqcy)."""
+        c = self.cfg
+        po = _f(po)
+        pom = po.copy(order="F") if pom is None else _f(pom)
+        qo = hostinit.q_from_p(c, self.amatoc, self.yporel, self.ddynoc, po)
+        qom = hostinit.q_from_p(c, self.amatoc, self.yporel, self.ddynoc, pom)
+        self.set_state(po, pom, qo, qom)
+        self.set_scalars(hostinit.constr(c, self.amatoc, po, pom))
+
+    def set_state(self, po=None, pom=None, qo=None, qom=None):
+        a = [_f(x) for x in (po, pom, qo, qom)]
+        check(self.L.qgcm_hip_set_state(self.h, *[_dp(x) for x in a]))
+
+    def get_state(self):
+        a = [self._f3() for _ in range(4)]
+        check(self.L.qgcm_hip_get_state(self.h, *[_dp(x) for x in a]))
+        return a
+
+    po = property(lambda self: self.get_state()[0])
+    pom = property(lambda self: self.get_state()[1])
+    qo = property(lambda self: self.get_state()[2])
+    qom = property(lambda self: self.get_state()[3])
+
+    def set_forcing(self, wekpo=None, entoc=None, xon=None):
+        w, e = _f(wekpo), _f(entoc)
+        x = None if xon is None else np.ascontiguousarray(xon, dtype=np.float64)
+        check(self.L.qgcm_hip_set_forcing(self.h, _dp(w), _dp(e), _dp(x)))
+
+    def set_cyc_forcing(self, txisoc, txinoc, enisoc=None, eninoc=None):
+        nl = self.cfg.nlo
+        es = np.zeros(nl - 1) if enisoc is None else np.ascontiguousarray(enisoc, dtype=np.float64)
+        en = np.zeros(nl - 1) if eninoc is None else np.ascontiguousarray(eninoc, dtype=np.float64)
+        check(self.L.qgcm_hip_set_cyc_forcing(self.h, float(txisoc), float(txinoc), _dp(es), _dp(en)))
+
+    def set_scalars(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        assert s.size == self.nscal
+        check(self.L.qgcm_hip_set_scalars(self.h, _dp(s)))
+
+    def get_scalars(self):
+        s = np.zeros(self.nscal)
+        check(self.L.qgcm_hip_get_scalars(self.h, _dp(s)))
+        return s
+
+    def get_inv_diag(self):
+        nl = self.cfg.nlo
+        x = np.zeros(nl)
+        cf = np.zeros(2 * nl + 1)
+        check(self.L.qgcm_hip_get_inv_diag(self.h, _dp(x), _dp(cf)))
+        n = 2 * (nl - 1) + 1 if self.cfg.cyclic else nl - 1
+        return x, cf[:n].copy()
+
+    # -- the path (same names as the reference's module procedures) ------------
+    def qgostep(self):
+        check(self.L.qgcm_hip_qgostep(self.h))
+
+    def ocinvq(self):
+        check(self.L.qgcm_hip_ocinvq(self.h))
+
+    def ocqbdy(self):
+        check(self.L.qgcm_hip_ocqbdy(self.h))
+
+    def lf_average(self):
+        check(self.L.qgcm_hip_lf_average(self.h))
+
+    def steps(self, n, s0=None):
+        """n whole ocean steps (q-gcm.F:1243-1249 + the averaging of :1328)."""
+        s0 = self.step_index if s0 is None else int(s0)
+        check(self.L.qgcm_hip_steps(self.h, s0, int(n)))
+        self.step_index = s0 + int(n)
+
+    def sync(self):
+        check(self.L.qgcm_hip_sync(self.h))
+
+    def helmholtz(self, wrk, boc):
+        """hsbxoc / hscyoc replacement (src/ocisubs.F:415-618); returns the solution."""
+        w = np.array(wrk, dtype=np.float64, order="F", copy=True)
+        b = np.ascontiguousarray(boc, dtype=np.float64)
+        check(self.L.qgcm_hip_helmholtz(self.h, _dp(w), _dp(b)))
+        return w
+
+    # -- measurement ------------------------------------------------------------
+    def time_steps(self, n, s0=None):
+        """HIP-event time (ms) of n steps on the handle's stream."""
+        s0 = self.step_index if s0 is None else int(s0)
+        ms = C.c_float()
+        check(self.L.qgcm_hip_time_steps(self.h, s0, int(n), C.byref(ms)))
+        self.step_index = s0 + int(n)
+        return ms.value
+
+    def profile_steps(self, n, s0=None):
+        """Per-kernel HIP-event totals over n eagerly launched steps:
+        {name: (total_ms, launches)}."""
+        s0 = self.step_index if s0 is None else int(s0)
+        cap = 32
+        ms = (C.c_double * cap)()
+        ln = (C.c_int * cap)()
+        names = (C.c_char_p * cap)()
+        nk = C.c_int(cap)
+        check(self.L.qgcm_hip_profile_steps(self.h, s0, int(n), ms, ln, names, C.byref(nk)))
+        self.step_index = s0 + int(n)
+        return {names[i].decode(): (ms[i], ln[i]) for i in range(nk.value)}
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        g = C.c_double()
+        check(self.L.qgcm_hip_copy_bandwidth(self.h, C.c_size_t(nbytes), int(reps), C.byref(g)))
+        return g.value

@@ -1,0 +1,80 @@
+"""Deterministic synthetic inputs (the reference's forcing blobs are not in the
+checkout): double-gyre / channel wind stress, Gaussian-eddy initial
+pressure, and the ocean-only Ekman pumping derived from the stress."""
+import numpy as np
+
+
+def wind_stress(cfg):
+    """tauxo, tauyo on the p-grid (m^2 s^-2), SURVEY 8d."""
+    nx, ny = cfg.nxpo, cfg.nypo
+    j = np.arange(ny, dtype=np.float64)
+    if cfg.cyclic:
+        prof = 1.0e-4 * np.sin(np.pi * j / (ny - 1)) ** 2
+    else:
+        prof = -1.0e-4 * np.cos(2.0 * np.pi * j / (ny - 1))
+    taux = np.asfortranarray(np.broadcast_to(prof[None, :], (nx, ny)).copy())
+    tauy = np.zeros((nx, ny), order="F")
+    return taux, tauy
+
+
+def wekpo_from_tau(cfg, tauxo, tauyo):
+    """Ocean-only Ekman pumping: wekto at T points and its p-point average
+    (src/xfosubs.F:138 hxofac, 566-645)."""
+    nx, ny = cfg.nxpo, cfg.nypo
+    hxofac = 0.5 * (1.0 / (cfg.dxo * cfg.fnot))
+    tx, ty = tauxo, tauyo
+    wt = hxofac * (ty[1:, 1:] + ty[1:, :-1] - (ty[:-1, 1:] + ty[:-1, :-1])
+                   + tx[1:, :-1] + tx[:-1, :-1] - (tx[1:, 1:] + tx[:-1, 1:]))
+    wp = np.zeros((nx, ny), order="F")
+    wp[1:-1, 1:-1] = 0.25 * (wt[:-1, :-1] + wt[:-1, 1:] + wt[1:, :-1] + wt[1:, 1:])
+    wp[1:-1, 0] = 0.5 * (wt[:-1, 0] + wt[1:, 0])
+    wp[1:-1, -1] = 0.5 * (wt[:-1, -1] + wt[1:, -1])
+    if cfg.cyclic:
+        wp[0, 1:-1] = 0.25 * (wt[-1, :-1] + wt[-1, 1:] + wt[0, :-1] + wt[0, 1:])
+        wp[0, 0] = 0.5 * (wt[-1, 0] + wt[0, 0])
+        wp[0, -1] = 0.5 * (wt[-1, -1] + wt[0, -1])
+        wp[-1, :] = wp[0, :]
+    else:
+        wp[0, 1:-1] = 0.5 * (wt[0, :-1] + wt[0, 1:])
+        wp[-1, 1:-1] = 0.5 * (wt[-1, :-1] + wt[-1, 1:])
+        wp[0, 0], wp[0, -1] = wt[0, 0], wt[0, -1]
+        wp[-1, 0], wp[-1, -1] = wt[-1, 0], wt[-1, -1]
+    return np.asfortranarray(wt), wp
+
+
+def tau_line_integrals(cfg, tauxo):
+    """txisoc, txinoc of the cyclic momentum constraints (xfosubs.F:655-671)."""
+    def line(v):
+        return 0.5 * v[0] + v[1:-1].sum() + 0.5 * v[-1]
+    txs = line(tauxo[:, 0] + tauxo[:, 1])
+    txn = line(tauxo[:, -2] + tauxo[:, -1])
+    return 0.5 * cfg.dxo * txs, 0.5 * cfg.dxo * txn
+
+
+def gaussian_eddy(cfg, amp=0.15, lfold=None, xc=0.4, yc=0.55, noise=0.0, seed=247):
+    """IC B / IC C of SURVEY 8d: surface Gaussian eddy (formula of the fork's restart
+    generator, src/k247_make_restart_q-gcm.F90:240-262), optional smoothed noise."""
+    nx, ny, nl = cfg.nxpo, cfg.nypo, cfg.nlo
+    if lfold is None:
+        lfold = max(8.0e4, 6.0 * cfg.dxo)
+    x = np.arange(nx)[:, None] * cfg.dxo
+    y = np.arange(ny)[None, :] * cfg.dyo
+    po = np.zeros((nx, ny, nl), order="F")
+    po[:, :, 0] = 9.8 * amp * np.exp(-((x - xc * cfg.xlo) ** 2 + (y - yc * cfg.ylo) ** 2) / lfold ** 2)
+    if cfg.cyclic:
+        # make the field exactly periodic in x and add a zonal-wave component
+        i = np.arange(nx)[:, None]
+        j = np.arange(ny)[None, :]
+        po[:, :, 0] += 0.3 * np.sin(2 * np.pi * i / (nx - 1)) * np.sin(np.pi * j / (ny - 1))
+        po[:, :, 1] = 0.2 * po[:, :, 0]
+        po[-1, :, :] = po[0, :, :]
+    if noise > 0.0:
+        rng = np.random.default_rng(seed)
+        for k in range(nl):
+            r = rng.uniform(-1.0, 1.0, size=(nx, ny))
+            s = r.copy()
+            s[1:-1, 1:-1] = 0.2 * (r[1:-1, 1:-1] + r[:-2, 1:-1] + r[2:, 1:-1] + r[1:-1, :-2] + r[1:-1, 2:])
+            po[:, :, k] += noise * np.abs(po[:, :, 0]).max() * s
+        if cfg.cyclic:
+            po[-1, :, :] = po[0, :, :]
+    return po

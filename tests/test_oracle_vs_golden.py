@@ -1,0 +1,127 @@
+"""Pins the C restatement (oracle/qgcm_oracle.c) to the golden vectors that were
+generated from the true reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from common import (CONFIG_NAMES, FIELDS, SNAPS, apply_inputs, load_golden, load_snapshot, make_oracle,
+                    preset, relerr, scal_err, state_errs)
+
+TOL_POINT = 0.0      # qgostep / ocqbdy / init q: same association order, no FMA -> bit exact
+TOL_SOLVE = 2e-13    # anything through the FFT-based Helmholtz solve (different FFT factorisation)
+
+
+@pytest.fixture(scope="module", params=CONFIG_NAMES)
+def case(request):
+    cfg = preset(request.param)
+    g = load_golden(request.param)
+    o = make_oracle(cfg, g["c_yporel"])
+    yield cfg, g, o
+    o.close()
+
+
+def test_yporel_formula(case):
+    cfg, g, _ = case
+    assert np.array_equal(cfg.yporel(), g["c_yporel"])
+
+
+def test_constants(case):
+    cfg, g, o = case
+    c = o.get_consts()
+    assert np.array_equal(c["amatoc"], g["c_amatoc"])
+    assert np.array_equal(c["bd2oc"], g["c_bd2oc"])
+    assert c["aoc"] == float(g["c_aoc"])
+    for k in ("ctl2moc", "ctm2loc", "rdm2oc"):
+        assert relerr(c[k], g["c_" + k]) < 5e-15, k
+
+
+def test_homog(case):
+    cfg, g, o = case
+    h = o.get_homog()
+    if cfg.cyclic:
+        big = max(np.abs(g["h_hc1soc"]).max(), np.abs(g["h_hc2noc"]).max())
+        for k in ("pch1oc", "pch2oc", "pbhoc", "aipcho", "hbsioc", "aipbho"):
+            assert relerr(h[k], g["h_" + k]) < 1e-13, k
+        for k in ("hc1soc", "hc2soc", "hc1noc", "hc2noc"):  # two of them are ~exp(-ylo/Rd): compare absolutely
+            assert np.abs(h[k] - g["h_" + k]).max() / big < 1e-13, k
+    else:
+        for k in ("ochom", "aipohs", "cdiffo", "cdhoc"):
+            assert relerr(h[k], g["h_" + k]) < 1e-13, k
+
+
+def test_init_q_and_scalars(case):
+    cfg, g, o = case
+    apply_inputs(o, g, cfg)
+    e = state_errs(o, g, "init")
+    assert all(v <= TOL_POINT for v in e.values()), e
+    assert scal_err(o, g, "init", cfg) < 1e-15
+
+
+def test_single_calls(case):
+    cfg, g, o = case
+    if "qgostep_po" not in g:
+        pytest.skip("per-call snapshots only stored for the tiny grids")
+    apply_inputs(o, g, cfg)
+    o.qgostep()
+    e = state_errs(o, g, "qgostep")
+    assert all(v <= TOL_POINT for v in e.values()), e
+    load_snapshot(o, g, "qgostep")
+    o.ocinvq()
+    e = state_errs(o, g, "ocinvq")
+    assert e["pom"] == 0.0 and e["qo"] == 0.0 and e["qom"] == 0.0 and e["po"] < TOL_SOLVE, e
+    assert scal_err(o, g, "ocinvq", cfg) < 1e-13
+    load_snapshot(o, g, "ocinvq")
+    o.ocqbdy()
+    e = state_errs(o, g, "ocqbdy")
+    assert all(v <= TOL_POINT for v in e.values()), e
+
+
+def test_whole_steps(case):
+    cfg, g, o = case
+    apply_inputs(o, g, cfg)
+    done = 0
+    for s in SNAPS[cfg.name]:
+        o.steps(done + 1, s - done)
+        done = s
+        e = state_errs(o, g, "steps%d" % s)
+        # free-running comparison: rounding differences of the solver grow slowly
+        assert all(v < 5e-12 for v in e.values()), (s, e)
+        assert scal_err(o, g, "steps%d" % s, cfg) < 1e-12
+
+
+def test_helmholtz(case):
+    cfg, g, o = case
+    assert relerr(o.helmholtz(g["helm_rhs"], g["helm_boc"]), g["helm_sol"]) < TOL_SOLVE
+    assert relerr(o.helmholtz(g["helm_rhs"], g["helm_boc0"]), g["helm_sol0"]) < TOL_SOLVE
+
+
+def test_fftpack_vectors():
+    g = load_golden("fftpack_eigmod")
+    for n in (3, 4, 5, 14, 47, 59, 95, 959):
+        assert relerr(ob.dsint(g["dsint_in_%d" % n]), g["dsint_out_%d" % n]) < 1e-14, n
+    for n in (4, 6, 9, 10, 48, 96, 384, 385):
+        f = ob.rfftf(g["drfft_in_%d" % n])
+        assert relerr(f, g["drfftf_out_%d" % n]) < 1e-14, n
+        assert relerr(ob.rfftb(g["drfftf_out_%d" % n]), g["drfftb_out_%d" % n]) < 1e-14, n
+
+
+def test_dsint_is_self_inverse():
+    # FFTPACK: dsint(dsint(x)) = 2(n+1) x  (fft.doc:342-344)
+    rng = np.random.default_rng(3)
+    for n in (7, 48, 959):
+        x = rng.standard_normal(n)
+        assert relerr(ob.dsint(ob.dsint(x)) / (2.0 * (n + 1)), x) < 1e-13
+
+
+def test_eigmod_vectors():
+    g = load_golden("fftpack_eigmod")
+    f0 = float(g["eig_fnot"])
+    for nl in (2, 3, 4):
+        tag = "eig%d" % nl
+        e = ob.eigmod(g[tag + "_gp"], g[tag + "_h"], f0)
+        assert np.array_equal(e["amatoc"], g[tag + "_amatoc"])
+        for k in ("rdm2oc", "ctl2moc", "ctm2loc"):
+            assert relerr(e[k], g[tag + "_" + k]) < 1e-14, (nl, k)
+        # cm2l * cl2m = identity (the reference prints this check, eigmode.f:478-505)
+        prod = e["ctm2loc"].T @ e["ctl2moc"].T
+        assert np.abs(prod - np.eye(nl)).max() < 1e-14
