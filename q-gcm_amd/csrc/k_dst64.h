@@ -1,0 +1,342 @@
+// k_dst64.h - K3 fast path: DST-I rows of length n = 64*M - 1, one wavefront per
+// row PAIR, no workgroup barriers.
+//
+// Same mathematics as k_dst.h (FFTPACK dsint restated: pre-twiddle, length
+// N = n+1 real FFT, running-sum post-process; src/fftpack/newbihar/dsint.f:16-40;
+// called from hsbxoc, src/ocisubs.F:461-463,494-499) with the complex FFT of
+// the packed row pair organised for a 64-lane wave:
+//
+//   N = 64*M,  n = 64*n1 + n2,  k = k1 + M*k2
+//   (1) lane n2 holds z[64*n1 + n2], n1 = 0..M-1, in registers: M-point DFT
+//       over n1 in registers (M = 15 as 3x5), twiddle W_N^(n2*k1);
+//   (2) the M independent 64-point FFTs over n2 run through LDS as two
+//       radix-8 passes (8 = contiguous / stride-8 accesses on a padded row);
+//   (3) conjugate-symmetric split of the two real spectra, FFTPACK's running
+//       sum as a wave scan (shuffles), results staged in LDS and stored with
+//       16-byte coalesced writes.
+// LDS traffic per row pair ~ 6 passes over 15 KB; everything is wave-synchronous
+// (LDS operations of one wave execute in order), so a workgroup is just four
+// independent waves.
+#pragma once
+#include "qgcm_dev.h"
+#include "k_dst.h" // cplx helpers
+
+#define D64_WAVES 4
+#define D64_NT (64 * D64_WAVES)
+#define D64_ROW 72 // padded length of one 64-point row (pad 1 per 8)
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.x * s, a.y * s}; }
+__device__ __forceinline__ cplx cmpi(cplx a) { return {-a.y, a.x}; } // * (+i)
+
+// forward 8-point DFT, y[c] = sum_a x[a] exp(-2 pi i a c / 8), in place
+__device__ __forceinline__ void dft8(cplx *x) {
+  const double r2 = 0.70710678118654752440;
+  cplx e0 = cadd(x[0], x[4]), o0 = csub(x[0], x[4]);
+  cplx e1 = cadd(x[1], x[5]), o1 = csub(x[1], x[5]);
+  cplx e2 = cadd(x[2], x[6]), o2 = csub(x[2], x[6]);
+  cplx e3 = cadd(x[3], x[7]), o3 = csub(x[3], x[7]);
+  // odd branch twiddles W8^a
+  cplx p1 = {r2 * (o1.x + o1.y), r2 * (o1.y - o1.x)};   // o1 * (1 - i)/sqrt2
+  cplx p2 = cmni(o2);                                   // o2 * (-i)
+  cplx p3 = {r2 * (o3.y - o3.x), -r2 * (o3.x + o3.y)};  // o3 * (-1 - i)/sqrt2
+  cplx t0 = cadd(e0, e2), t1 = csub(e0, e2), t2 = cadd(e1, e3), t3 = cmni(csub(e1, e3));
+  x[0] = cadd(t0, t2);
+  x[4] = csub(t0, t2);
+  x[2] = cadd(t1, t3);
+  x[6] = csub(t1, t3);
+  cplx u0 = cadd(o0, p2), u1 = csub(o0, p2), u2 = cadd(p1, p3), u3 = cmni(csub(p1, p3));
+  x[1] = cadd(u0, u2);
+  x[5] = csub(u0, u2);
+  x[3] = cadd(u1, u3);
+  x[7] = csub(u1, u3);
+}
+
+__device__ __forceinline__ void dft3(cplx &a0, cplx &a1, cplx &a2) {
+  const double s3 = 0.86602540378443864676;
+  cplx t1 = cadd(a1, a2);
+  cplx t2 = {a0.x - 0.5 * t1.x, a0.y - 0.5 * t1.y};
+  cplx d = csub(a1, a2);
+  cplx t3 = {s3 * d.y, -s3 * d.x};
+  a0 = cadd(a0, t1);
+  a1 = cadd(t2, t3);
+  a2 = csub(t2, t3);
+}
+
+__device__ __forceinline__ void dft5(cplx &a0, cplx &a1, cplx &a2, cplx &a3, cplx &a4) {
+  const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+  const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+  cplx t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+  cplx m1 = {a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y};
+  cplx m2 = {a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y};
+  cplx n1 = {s1 * t3.y + s2 * t4.y, -(s1 * t3.x + s2 * t4.x)};
+  cplx n2 = {s2 * t3.y - s1 * t4.y, -(s2 * t3.x - s1 * t4.x)};
+  a0 = {a0.x + t1.x + t2.x, a0.y + t1.y + t2.y};
+  a1 = cadd(m1, n1);
+  a4 = csub(m1, n1);
+  a2 = cadd(m2, n2);
+  a3 = csub(m2, n2);
+}
+
+// in-register forward DFT of length M over a[0..M-1] (natural order in and out)
+template <int M>
+__device__ __forceinline__ void dftM(cplx *a);
+
+template <>
+__device__ __forceinline__ void dftM<3>(cplx *a) {
+  dft3(a[0], a[1], a[2]);
+}
+
+// 15 = 3 x 5 Cooley-Tukey: n = 5*na + nb, k = ka + 3*kb
+template <>
+__device__ __forceinline__ void dftM<15>(cplx *a) {
+  // W15^e = exp(-2 pi i e / 15) for e = 1,2,3,4,6,8
+  const cplx w1 = {0.9135454576426008955, -0.4067366430758002078};
+  const cplx w2 = {0.6691306063588582138, -0.7431448254773942350};
+  const cplx w3 = {0.3090169943749474241, -0.9510565162951535721};
+  const cplx w4 = {-0.1045284632676534714, -0.9945218953682733369};
+  const cplx w6 = {-0.8090169943749474241, -0.5877852522924731292};
+  const cplx w8 = {-0.9781476007338056379, 0.2079116908177593371};
+  // radix-3 over na for each nb: (a[nb], a[5+nb], a[10+nb]) -> t[ka][nb] stored at a[5*ka + nb]
+#pragma unroll
+  for (int nb = 0; nb < 5; ++nb) dft3(a[nb], a[5 + nb], a[10 + nb]);
+  // twiddle W15^(nb*ka)
+  a[5 + 1] = cmul(a[5 + 1], w1);
+  a[5 + 2] = cmul(a[5 + 2], w2);
+  a[5 + 3] = cmul(a[5 + 3], w3);
+  a[5 + 4] = cmul(a[5 + 4], w4);
+  a[10 + 1] = cmul(a[10 + 1], w2);
+  a[10 + 2] = cmul(a[10 + 2], w4);
+  a[10 + 3] = cmul(a[10 + 3], w6);
+  a[10 + 4] = cmul(a[10 + 4], w8);
+  // radix-5 over nb for each ka -> X[ka + 3*kb] at a[5*ka + kb]
+#pragma unroll
+  for (int ka = 0; ka < 3; ++ka) dft5(a[5 * ka], a[5 * ka + 1], a[5 * ka + 2], a[5 * ka + 3], a[5 * ka + 4]);
+  // reorder to natural k = ka + 3*kb
+  cplx t[15];
+#pragma unroll
+  for (int ka = 0; ka < 3; ++ka)
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) t[ka + 3 * kb] = a[5 * ka + kb];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) a[k] = t[k];
+}
+
+// grid: (ceil(npairs / 4), nlayers), block 256 = 4 independent waves
+template <int M, bool ROWSUM>
+__global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
+  constexpr int N = 64 * M, n = N - 1, NS2 = n / 2; // n odd: NS2 = N/2 - 1 = K
+  __shared__ __align__(16) cplx Fsh[D64_WAVES][M * D64_ROW];
+  __shared__ __align__(16) cplx W64sh[D64_WAVES][64]; // exp(-2 pi i t / 64), per wave copy
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int ny = P.g.ny, ldw = P.g.ldw;
+  const int m = blockIdx.y;
+  const int pair = blockIdx.x * D64_WAVES + wv;
+  const int ja = 2 + 2 * pair;
+  if (ja > ny - 1) return; // whole wave leaves; no workgroup barrier is ever used
+  const bool has_b = (ja + 1 <= ny - 1);
+  double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
+  double *rowb = rowa + ldw;
+  cplx *F = Fsh[wv];
+  double *raw = reinterpret_cast<double *>(F); // rows a, b: raw[0..N-1], raw[N..2N-1]
+
+  // Everything this lane will need from global tables is requested up front so
+  // that it arrives together with the rows: W_N^(lane*k1), the dsint sine
+  // factors, and this wave's copy of the 64-point twiddles.
+  cplx tw1[M];
+#pragma unroll
+  for (int k1 = 1; k1 < M; ++k1) {
+    double2 w = P.twid[lane * k1];
+    tw1[k1] = {w.x, w.y};
+  }
+  double snv[M];
+#pragma unroll
+  for (int n1 = 0; n1 < M; ++n1) {
+    const int j = 64 * n1 + lane;
+    snv[n1] = P.sintab[(j <= NS2) ? j : N - j];
+  }
+  cplx *W64 = W64sh[wv];
+  {
+    double2 w = P.twid[M * lane];
+    W64[lane] = {w.x, w.y};
+  }
+
+  // ---- (0) rows -> LDS, 16-byte coalesced ---------------------------------
+  {
+    const double2 *ga = reinterpret_cast<const double2 *>(rowa);
+    const double2 *gb = reinterpret_cast<const double2 *>(rowb);
+    double2 *ra = reinterpret_cast<double2 *>(raw);
+    double2 *rb = reinterpret_cast<double2 *>(raw + N);
+#pragma unroll
+    for (int u = 0; u < (N / 2 + 63) / 64; ++u) {
+      int t = lane + 64 * u;
+      if (t < N / 2) {
+        ra[t] = ga[t];
+        rb[t] = has_b ? gb[t] : double2{0.0, 0.0};
+      }
+    }
+  }
+  wave_lds_sync();
+
+  // ---- (1) pre-twiddle (dsint.f:19-33) into registers: a[n1] = z[64*n1 + lane]
+  cplx a[M];
+#pragma unroll
+  for (int n1 = 0; n1 < M; ++n1) {
+    const int j = 64 * n1 + lane;
+    const int k = (j <= NS2) ? j : N - j;
+    cplx z;
+    if (j == 0) {
+      z = {0.0, 0.0};
+    } else if (j == NS2 + 1) {
+      z = {4.0 * raw[j - 1], 4.0 * raw[N + j - 1]};
+    } else {
+      double xa = raw[k - 1], xac = raw[n - k];
+      double xb = raw[N + k - 1], xbc = raw[N + n - k];
+      double sn = snv[n1];
+      double t1a = xa - xac, t2a = sn * (xa + xac);
+      double t1b = xb - xbc, t2b = sn * (xb + xbc);
+      if (j <= NS2) z = {t1a + t2a, t1b + t2b};
+      else z = {t2a - t1a, t2b - t1b};
+    }
+    a[n1] = z;
+  }
+  dftM<M>(a);
+  wave_lds_sync(); // every lane has finished reading the raw rows
+#pragma unroll
+  for (int k1 = 0; k1 < M; ++k1) {
+    cplx v = (k1 == 0) ? a[0] : cmul(a[k1], tw1[k1]);
+    F[k1 * D64_ROW + lane + (lane >> 3)] = v;
+  }
+  wave_lds_sync();
+
+  // ---- (2a) radix-8 over a (n2 = 8a + b), twiddle W64^(b*c), in place -------
+  constexpr int NBF = M * 8;
+#pragma unroll
+  for (int rd = 0; rd < (NBF + 63) / 64; ++rd) {
+    const int id = lane + 64 * rd;
+    if (id < NBF) {
+      const int k1 = id >> 3, b = id & 7;
+      cplx *row = F + k1 * D64_ROW + b;
+      cplx x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = row[9 * q];
+      dft8(x);
+#pragma unroll
+      for (int c = 1; c < 8; ++c) x[c] = cmul(x[c], W64[b * c]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) row[9 * c] = x[c];
+    }
+  }
+  wave_lds_sync();
+  // ---- (2b) radix-8 over b for fixed c: positions 9c + b -> 9c + d (k2 = c + 8d)
+#pragma unroll
+  for (int rd = 0; rd < (NBF + 63) / 64; ++rd) {
+    const int id = lane + 64 * rd;
+    if (id < NBF) {
+      const int k1 = id >> 3, c = id & 7;
+      cplx *row = F + k1 * D64_ROW + 9 * c;
+      cplx x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = row[q];
+      dft8(x);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) row[d] = x[d];
+    }
+  }
+  wave_lds_sync();
+
+  // ---- (3) split + FFTPACK post-process (dsint.f:37-44) ----------------------
+  // Z[k], k = k1 + M*k2, k2 = c + 8d, lives at F[k1*72 + 9c + d]
+  auto zidx = [](int k) {
+    int k1 = k % M, k2 = k / M;
+    return k1 * D64_ROW + 9 * (k2 & 7) + (k2 >> 3);
+  };
+  constexpr int K = NS2;              // odd outputs b[2k+1], k = 1..K
+  constexpr int CH = (K + 63) / 64;   // k's per lane
+  const int k0 = 1 + lane * CH;
+  double rea[CH], ima[CH], reb[CH], imb[CH];
+  double suma = 0.0, sumb = 0.0;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int k = k0 + t;
+    if (k <= K) {
+      cplx z1 = F[zidx(k)], z2 = F[zidx(N - k)];
+      rea[t] = 0.5 * (z1.x + z2.x);
+      ima[t] = 0.5 * (z1.y - z2.y);
+      reb[t] = 0.5 * (z1.y + z2.y);
+      imb[t] = -0.5 * (z1.x - z2.x);
+      suma += rea[t];
+      sumb += reb[t];
+    } else {
+      rea[t] = ima[t] = reb[t] = imb[t] = 0.0;
+    }
+  }
+  const cplx z0 = F[0];
+  // inclusive wave scan of the per-lane partial sums
+  double inca = suma, incb = sumb;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double va = __shfl_up(inca, off), vb = __shfl_up(incb, off);
+    if (lane >= off) {
+      inca += va;
+      incb += vb;
+    }
+  }
+  const double b1a = 0.5 * z0.x, b1b = 0.5 * z0.y;
+  double runa = b1a + (inca - suma), runb = b1b + (incb - sumb);
+  wave_lds_sync(); // all spectrum reads done: reuse the buffer for the output rows
+  double rsa = 0.0, rsb = 0.0;
+  if (lane == 0) {
+    raw[0] = b1a;
+    raw[N] = b1b;
+    raw[N - 1] = 0.0; // padding slots (element n of each row is unused)
+    raw[2 * N - 1] = 0.0;
+    rsa = b1a;
+    rsb = b1b;
+  }
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const int k = k0 + t;
+    if (k <= K) {
+      runa += rea[t];
+      runb += reb[t];
+      raw[2 * k - 1] = -ima[t];
+      raw[2 * k] = runa;
+      raw[N + 2 * k - 1] = -imb[t];
+      raw[N + 2 * k] = runb;
+      rsa += runa - ima[t];
+      rsb += runb - imb[t];
+    }
+  }
+  wave_lds_sync();
+  {
+    double2 *ga = reinterpret_cast<double2 *>(rowa);
+    double2 *gb = reinterpret_cast<double2 *>(rowb);
+    const double2 *ra = reinterpret_cast<const double2 *>(raw);
+    const double2 *rb = reinterpret_cast<const double2 *>(raw + N);
+#pragma unroll
+    for (int u = 0; u < (N / 2 + 63) / 64; ++u) {
+      int t = lane + 64 * u;
+      if (t < N / 2) {
+        ga[t] = ra[t];
+        if (has_b) gb[t] = rb[t];
+      }
+    }
+  }
+  if (ROWSUM) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      rsa += __shfl_down(rsa, off);
+      rsb += __shfl_down(rsb, off);
+    }
+    if (lane == 0) {
+      P.rowsum[(long)m * ny + (ja - 1)] = rsa;
+      if (has_b) P.rowsum[(long)m * ny + ja] = rsb;
+    }
+  }
+}

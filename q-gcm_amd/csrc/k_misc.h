@@ -41,16 +41,25 @@ __device__ inline double qg_block_sum(double v, double *red, int tid) {
 }
 
 __global__ __launch_bounds__(CS_NT) void k_constr_box(const QgConstrParams P) {
-  __shared__ double red[CS_NT];
+  __shared__ double red[QG_MAXL][CS_NT];
   __shared__ double xin[QG_MAXL];
   const int tid = threadIdx.x;
   const int nl = P.g.nl, ny = P.g.ny;
+  // all modes at once: independent loads first, then one fixed-order tree per mode
+  double s[QG_MAXL];
   for (int m = 0; m < nl; ++m) {
-    double s = 0.0;
-    for (int j = 1 + tid; j <= ny - 2; j += CS_NT) s += P.rowsum[(long)m * ny + j];
-    double tot = qg_block_sum(s, red, tid);
-    if (tid == 0) xin[m] = tot * P.dxo * P.dyo;
+    double acc = 0.0;
+    for (int j = 1 + tid; j <= ny - 2; j += CS_NT) acc += P.rowsum[(long)m * ny + j];
+    s[m] = acc;
   }
+  for (int m = 0; m < nl; ++m) red[m][tid] = s[m];
+  __syncthreads();
+  for (int off = CS_NT / 2; off > 0; off >>= 1) {
+    if (tid < off)
+      for (int m = 0; m < nl; ++m) red[m][tid] += red[m][tid + off];
+    __syncthreads();
+  }
+  if (tid < nl) xin[tid] = red[tid][0] * P.dxo * P.dyo;
   __syncthreads();
   if (tid == 0) {
     QgScalars *sc = P.sc;
@@ -105,11 +114,8 @@ __global__ __launch_bounds__(CS_NT) void k_constr_box(const QgConstrParams P) {
 // Traffic: read wrk (nl) + ochom (nl-1), write po (nl).
 // ---------------------------------------------------------------------------
 template <int NL>
-__global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P) {
+__device__ __forceinline__ void unpack_point(const QgUnpackParams &P, int gi, int gj, double *pl) {
   const int nx = P.g.nx, ny = P.g.ny;
-  const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  const int gj = blockIdx.y + 1;
-  if (gi > nx || gj > ny) return;
   const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
   const bool inner = (gi >= 2 && gi <= nx - 1 && gj >= 2 && gj <= ny - 1);
   const long ow = (long)(gj - 1) * P.g.ldw + (gi - 2);
@@ -122,10 +128,47 @@ __global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P) {
   }
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
-    double pl = 0.0;
+    double v = 0.0;
 #pragma unroll
-    for (int m = 0; m < NL; ++m) pl = pl + P.ctm2l[m + NL * k] * pm[m];
-    P.pnew[P.g.fstride * k + o] = pl;
+    for (int m = 0; m < NL; ++m) v = v + P.ctm2l[m + NL * k] * pm[m];
+    pl[k] = v;
+  }
+}
+
+// BDY = true additionally writes the boundary PV of the new pressure (ocqbdy,
+// src/vorsubs.F:245-388) from the same threads: qgcm_hip_steps uses it to save
+// a launch; the stand-alone entry points keep unpack and ocqbdy separate.
+template <int NL, bool BDY>
+__global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P, const QgBdyParams B) {
+  const int nx = P.g.nx, ny = P.g.ny;
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const int gj = blockIdx.y + 1;
+  if (gi > nx || gj > ny) return;
+  const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
+  double pl[NL];
+  unpack_point<NL>(P, gi, gj, pl);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) P.pnew[P.g.fstride * k + o] = pl[k];
+  if (BDY) {
+    const bool ns = (gj == 1 || gj == ny);
+    const bool we = (gi == 1 || gi == nx);
+    if (ns || we) {
+      const int ii = ns ? gi : (gi == 1 ? 2 : nx - 1);
+      const int jj = ns ? (gj == 1 ? 2 : ny - 1) : gj;
+      double pin[NL];
+      unpack_point<NL>(P, ii, jj, pin);
+      const double by = B.beta * B.yporel[gj - 1];
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        double ap;
+        if (k == 0) ap = B.f0A[0] * pl[0] + B.f0A[NL] * pl[1];
+        else if (k == NL - 1) ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k];
+        else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
+        double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
+        if (k == NL - 1) q = q + B.ddynoc[o];
+        B.qo[P.g.fstride * k + o] = q;
+      }
+    }
   }
 }
 

@@ -10,6 +10,12 @@
 // the radius-3 halo of pom and the radius-1 halos of po, qo are staged in
 // LDS, Del^2 / Del^4 are built in LDS with the reference's boundary rules,
 // and each thread finishes Del^6 + Jacobian for its points in registers.
+// The global loads of layer k+1 (and of the point-wise epilogue operands) are
+// issued into registers before layer k is computed, so a workgroup always
+// has loads in flight (software pipelining across layers).
+// Workgroups are renumbered so that each XCD (blockIdx mod 8) sweeps a
+// contiguous band of tile rows: the halo rows re-read by vertically adjacent
+// tiles then hit that XCD's own L2 instead of being re-fetched.
 // Expression association order is the reference's, and the library is built
 // with -ffp-contract=off, so qgostep reproduces the CPU reference bit for bit.
 //
@@ -39,6 +45,8 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   constexpr int W3 = TX + 6, H3 = TY + 6; // pom tile, halo 3
   constexpr int W2 = TX + 4, H2 = TY + 4; // d2 tile, halo 2
   constexpr int W1 = TX + 2, H1 = TY + 2; // d4 / po / qo tiles, halo 1
+  constexpr int N3 = (H3 * W3 + TEND_NT - 1) / TEND_NT; // staged elements per thread
+  constexpr int N1 = (H1 * W1 + TEND_NT - 1) / TEND_NT;
   __shared__ double sp[H3 * W3];
   __shared__ double sd2[H2 * W2];
   __shared__ double sd4[H1 * W1];
@@ -48,50 +56,97 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt, ldx = P.g.ldx;
   const long fs = P.g.fstride;
   const int tid = threadIdx.x;
-  const int i0 = blockIdx.x * TX + 1; // first global i of the tile (1-based)
-  const int j0 = blockIdx.y * TY + 1;
+  // ---- XCD-aware tile numbering ------------------------------------------
+  const int gx = (nx + TX - 1) / TX, gy = (ny + TY - 1) / TY;
+  const int ntiles = gx * gy;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= ntiles || (int)(blockIdx.x >> 3) >= per_xcd) return;
+  const int i0 = (tile % gx) * TX + 1; // first global i of the tile (1-based)
+  const int j0 = (tile / gx) * TY + 1;
   const int tx = tid % TX;
   const int ty0 = tid / TX; // 0..3
   constexpr int RPT = TY / (TEND_NT / TX); // rows per thread
   const double bcf = P.bcfaco, dxom2 = P.dxom2;
 
+  // ---- global offsets of the elements this thread stages (same for every layer)
+  long o3[N3], o1[N1];
+#pragma unroll
+  for (int e = 0; e < N3; ++e) {
+    int idx = tid + e * TEND_NT;
+    int lx = idx % W3, ly = idx / W3;
+    int gi = i0 - 3 + lx, gj = j0 - 3 + ly;
+    bool ok = idx < H3 * W3 && gj >= 1 && gj <= ny && (CYC ? (gi >= -2 && gi <= nx + 3) : (gi >= 1 && gi <= nx));
+    o3[e] = ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
+  }
+#pragma unroll
+  for (int e = 0; e < N1; ++e) {
+    int idx = tid + e * TEND_NT;
+    int lx = idx % W1, ly = idx / W1;
+    int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
+    bool ok = idx < H1 * W1 && gj >= 1 && gj <= ny && (CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx));
+    o1[e] = ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
+  }
+  double r3[N3], rp[N1], rq[N1];
+#pragma unroll
+  for (int e = 0; e < N3; ++e) r3[e] = o3[e] >= 0 ? P.pom[o3[e]] : 0.0;
+#pragma unroll
+  for (int e = 0; e < N1; ++e) {
+    rp[e] = o1[e] >= 0 ? P.po[o1[e]] : 0.0;
+    rq[e] = o1[e] >= 0 ? P.qo[o1[e]] : 0.0;
+  }
+  // ---- epilogue operands of this thread's own points (prefetched) -----------
+  double e_qm[NL][RPT], e_qo[NL][RPT], e_wek[RPT], e_ent[RPT], e_ddy[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    int ly = ty0 + r * (TEND_NT / TX);
+    int gi = i0 + tx, gj = j0 + ly;
+    bool in = gi <= nx && gj <= ny;
+    long o = in ? (long)(gj - 1) * ldx + (gi - 1) : 0;
+    bool row = in && (gj == 1 || gj == ny);
+    e_wek[r] = in ? P.wekpo[o] : 0.0;
+    e_ent[r] = in ? P.entoc[o] : 0.0;
+    e_ddy[r] = in ? P.ddynoc[o] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      e_qm[k][r] = in ? P.qnew[fs * k + o] : 0.0;
+      e_qo[k][r] = row ? P.qo[fs * k + o] : 0.0;
+    }
+  }
+
   double dq[NL][RPT];
   double d2bot[RPT];
 
+#pragma unroll
   for (int k = 0; k < NL; ++k) {
-    const double *pom = P.pom + fs * k;
-    const double *po = P.po + fs * k;
-    const double *qo = P.qo + fs * k;
-    // ---- stage tiles -------------------------------------------------
-    for (int idx = tid; idx < H3 * W3; idx += TEND_NT) {
-      int lx = idx % W3, ly = idx / W3;
-      int gi = i0 - 3 + lx, gj = j0 - 3 + ly;
-      double v = 0.0;
-      if (gj >= 1 && gj <= ny) {
-        if (CYC) {
-          if (gi >= -2 && gi <= nx + 3) v = pom[(long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1)];
-        } else if (gi >= 1 && gi <= nx) {
-          v = pom[(long)(gj - 1) * ldx + (gi - 1)];
-        }
-      }
-      sp[idx] = v;
+    // ---- registers -> LDS tiles of layer k --------------------------------
+#pragma unroll
+    for (int e = 0; e < N3; ++e) {
+      int idx = tid + e * TEND_NT;
+      if (idx < H3 * W3) sp[idx] = r3[e];
     }
-    for (int idx = tid; idx < H1 * W1; idx += TEND_NT) {
-      int lx = idx % W1, ly = idx / W1;
-      int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
-      double vp = 0.0, vq = 0.0;
-      if (gj >= 1 && gj <= ny) {
-        bool ok = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
-        if (ok) {
-          long o = (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1);
-          vp = po[o];
-          vq = qo[o];
-        }
+#pragma unroll
+    for (int e = 0; e < N1; ++e) {
+      int idx = tid + e * TEND_NT;
+      if (idx < H1 * W1) {
+        spo[idx] = rp[e];
+        sqo[idx] = rq[e];
       }
-      spo[idx] = vp;
-      sqo[idx] = vq;
     }
     __syncthreads();
+    // ---- issue the loads of layer k+1 (they fly while layer k is computed)
+    if (k + 1 < NL) {
+      const double *pom = P.pom + fs * (k + 1);
+      const double *po = P.po + fs * (k + 1);
+      const double *qo = P.qo + fs * (k + 1);
+#pragma unroll
+      for (int e = 0; e < N3; ++e) r3[e] = o3[e] >= 0 ? pom[o3[e]] : 0.0;
+#pragma unroll
+      for (int e = 0; e < N1; ++e) {
+        rp[e] = o1[e] >= 0 ? po[o1[e]] : 0.0;
+        rq[e] = o1[e] >= 0 ? qo[o1[e]] : 0.0;
+      }
+    }
     // ---- Del^2(pom) on the halo-2 region (qgosubs.F:94-127) ----------
     for (int idx = tid; idx < H2 * W2; idx += TEND_NT) {
       int lx = idx % W2, ly = idx / W2;
@@ -149,7 +204,7 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
       dq[k][r] = val;
       if (k == NL - 1) d2bot[r] = sd2[(ly + 2) * W2 + (tx + 2)];
     }
-    __syncthreads();
+    if (k + 1 < NL) __syncthreads();
   }
 
   // ---- forcing, bottom drag, leapfrog, projection ----------------------
@@ -162,25 +217,25 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
     if (gj == 1 || gj == ny) {
       // rows not stepped: the new-qo buffer keeps qo (qgosubs.F:214-219)
 #pragma unroll
-      for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = P.qo[fs * k + o];
+      for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = e_qo[k][r];
       continue;
     }
-    double ent = P.entoc[o];
+    double ent = e_ent[r];
     double qdot[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) qdot[k] = dq[k][r];
-    qdot[0] = dq[0][r] + P.fohfac[0] * (P.wekpo[o] - ent);
+    qdot[0] = dq[0][r] + P.fohfac[0] * (e_wek[r] - ent);
     qdot[1] = dq[1][r] + P.fohfac[1] * ent;
     qdot[NL - 1] = qdot[NL - 1] - P.bdrfac * d2bot[r];
     double ql[NL];
     double betay = P.beta * P.yporel[gj - 1];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      double qn = P.qnew[fs * k + o] + P.tdto * qdot[k]; // qom + tdto*qdot
+      double qn = e_qm[k][r] + P.tdto * qdot[k]; // qom + tdto*qdot
       P.qnew[fs * k + o] = qn;
       ql[k] = qn - betay;
     }
-    ql[NL - 1] = ql[NL - 1] - P.ddynoc[o];
+    ql[NL - 1] = ql[NL - 1] - e_ddy[r];
     int c = CYC ? gi - 1 : gi - 2;
     if (c >= 0 && c < P.g.nk) {
 #pragma unroll

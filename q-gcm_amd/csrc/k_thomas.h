@@ -4,8 +4,10 @@
 //     aoc*u(j-1) + boc(i)*u(j) + aoc*u(j+1) = rhs(i,j),  j = 2..nypo-1
 // is solved by the Thomas algorithm (src/ocisubs.F:470-488 box, 575-593
 // cyclic) and scaled by ftnorm.  The pivots betinv(j) = 1/(boc - aoc*gam(j))
-// depend only on (boc, j): they are tabulated once (host, same recurrence and
-// rounding as the reference) in `bet`, which removes every divide.
+// depend only on (boc, j).  The host tabulates the pivot entering each chunk
+// (same recurrence and rounding as the reference); every thread re-runs the
+// recurrence for its R rows (IEEE divides, identical values) while its row
+// loads are in flight, so no full-size pivot table is streamed.
 //
 // Parallel formulation: both sweeps are first-order linear recurrences
 //     forward : u_r = (w_r - aoc*u_{r-1}) * bet_r
@@ -17,8 +19,7 @@
 // maps are composed through LDS, and the sweep is re-run from the true
 // inflow - so each row is read once and written once.
 //
-// Algorithmic traffic: read w + write u (16 B per point); the pivot table adds
-// 8 B per point of re-read (cache resident for the 5 km grid).
+// Algorithmic traffic: read w + write u (16 B per point).
 #pragma once
 #include "qgcm_dev.h"
 
@@ -42,7 +43,6 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const bool kok = k < P.g.nk;
   const double a = P.aoc;
   double *wcol = P.wrk + P.g.wstride * m + (long)ldw + k;      // row j=2
-  const double *bcol = P.bet + P.g.wstride * m + (long)ldw + k;
   const int r0 = c * R;
 
   double w[R], b[R];
@@ -51,7 +51,22 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     int r = r0 + t;
     bool ok = kok && r < nr;
     w[t] = ok ? wcol[(long)r * ldw] : 0.0;
-    b[t] = ok ? bcol[(long)r * ldw] : 0.0;
+  }
+  // pivots of this chunk: betc = betinv of the row before the chunk (src/ocisubs.F:472-477)
+  {
+    const double boc = kok ? P.boc[(long)m * ldw + k] : 1.0;
+    double betinv = kok ? P.betc[((long)m * TH_NC + c) * ldw + k] : 0.0;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      int r = r0 + t;
+      if (r == 0) {
+        betinv = 1.0 / boc;
+      } else {
+        double gam = a * betinv;
+        betinv = 1.0 / (boc - a * gam);
+      }
+      b[t] = (kok && r < nr) ? betinv : 0.0;
+    }
   }
   // ---- forward: local affine map (zero inflow) ---------------------------
   double C = 0.0, D = 1.0;

@@ -9,7 +9,7 @@
 //                 128-B aligned row of ldw doubles per (j,m):
 //                 box:    c = i-2  for interior i=2..nxpo-1 (nk = nxto-1 sine coeffs)
 //                 cyclic: c = i-1  for i=1..nxto            (nk = nxto, own spectral order)
-//   bet(c,j,m)    Thomas table betinv (same layout as wrk), time-invariant.
+//   boc(c,m), betc(c,chunk,m)  Thomas diagonal and per-chunk entry pivots (small).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/qgcm_hip.h"
@@ -77,7 +77,8 @@ struct QgDstParams {
 struct QgThomasParams {
   QgGeom g;
   double *wrk;
-  const double *bet; // betinv table
+  const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index
+  const double *betc; // (ldw, TH_NC, nlayers): pivot entering each chunk of rows
   double aoc, ftnorm;
   int nlayers;
 };

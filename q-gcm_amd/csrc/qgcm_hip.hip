@@ -14,6 +14,7 @@
 #include "qgcm_dev.h"
 #include "k_tend.h"
 #include "k_dst.h"
+#include "k_dst64.h"
 #include "k_thomas.h"
 #include "k_misc.h"
 
@@ -43,7 +44,9 @@ struct qgcm_hip_ctx {
   double *p[2], *q[2];
   int ip, iq; // p[ip] = po, p[ip^1] = pom ; q[iq] = qo, q[iq^1] = qom
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
-  double *wrk, *bet, *bet_tmp, *rowsum;
+  double *wrk, *rowsum;
+  double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
+  int thR;                                 // rows per chunk of the Thomas kernel
   double *pch1, *pch2, *pbh;
   QgScalars *sc;
   double2 *twid;
@@ -51,10 +54,13 @@ struct qgcm_hip_ctx {
   int fftN, nfac, fac[QG_MAXFAC];
   QgConstr cs;
   bool grid_set, homog_set;
+  bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
   bool profiling;
   hipEvent_t ev0, ev1;
+  std::vector<hipEvent_t> evpool; // pairs, drained once per step (no host sync between kernels)
+  std::vector<int> evkid;
   double kms[KN_COUNT];
   int klaunch[KN_COUNT];
   // graphs keyed by (ip, iq, phase)
@@ -138,7 +144,9 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->wekpo, F) || dalloc(&c->entoc, F) || dalloc(&c->ddynoc, F)) return 1;
   if (dalloc(&c->ochom, F * (g.nl - 1))) return 1;
   if (dalloc(&c->yporel, g.ny)) return 1;
-  if (dalloc(&c->wrk, W * g.nl) || dalloc(&c->bet, W * g.nl) || dalloc(&c->bet_tmp, W)) return 1;
+  if (dalloc(&c->wrk, W * g.nl)) return 1;
+  if (dalloc(&c->boc, (size_t)g.ldw * g.nl) || dalloc(&c->betc, (size_t)g.ldw * TH_NC * g.nl)) return 1;
+  if (dalloc(&c->boc_tmp, (size_t)g.ldw) || dalloc(&c->betc_tmp, (size_t)g.ldw * TH_NC)) return 1;
   if (dalloc(&c->rowsum, (size_t)g.ny * g.nl)) return 1;
   if (dalloc(&c->pch1, (size_t)g.ny * g.nl) || dalloc(&c->pch2, (size_t)g.ny * g.nl) || dalloc(&c->pbh, g.ny)) return 1;
   HIPCHECK(hipMalloc((void **)&c->sc, sizeof(QgScalars)));
@@ -146,6 +154,10 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   c->twid = nullptr;
   c->sintab = nullptr;
   c->grid_set = c->homog_set = false;
+  {
+    const char *e = getenv("QGCM_HIP_GENERIC_DST");
+    c->force_generic_dst = e && e[0] == '1';
+  }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
   HIPCHECK(hipEventCreate(&c->ev1));
@@ -160,27 +172,41 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   hipStreamSynchronize(c->stream);
   for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
-                    c->wrk,  c->bet,  c->bet_tmp, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
+                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
   hipFree(c->sc);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->evpool) hipEventDestroy(e);
   hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
 
-// Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477
-static void build_bet(const QgGeom &g, double aoc, const double *boc /* per spectral index */, double *tab /* ny*ldw */) {
+static int thomas_rows_per_chunk(int ny) {
+  const int need = (ny - 2 + TH_NC - 1) / TH_NC;
+  for (int r : {1, 2, 4, 8, 16, 32})
+    if (need <= r) return r;
+  return -1;
+}
+
+// Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477; only the pivot
+// entering each chunk of R rows is kept (the kernel re-runs the recurrence).
+static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* per spectral index */,
+                       double *boc_out /* ldw */, double *betc /* TH_NC*ldw */) {
+  const int nr = g.ny - 2;
   for (int k = 0; k < g.nk; ++k) {
-    double betinv = 1.0 / boc[k];
-    tab[(size_t)1 * g.ldw + k] = betinv; // row j=2
-    for (int j = 3; j <= g.ny - 1; ++j) {
-      double gam = aoc * betinv;
-      betinv = 1.0 / (boc[k] - aoc * gam);
-      tab[(size_t)(j - 1) * g.ldw + k] = betinv;
+    boc_out[k] = boc[k];
+    double betinv = 1.0 / boc[k]; // row r = 0
+    for (int r = 0; r < nr; ++r) {
+      if (r > 0) {
+        double gam = aoc * betinv;
+        betinv = 1.0 / (boc[k] - aoc * gam);
+      }
+      // betinv is now the pivot of row r; it enters the chunk that starts at r+1
+      if ((r + 1) % R == 0 && (r + 1) / R < TH_NC) betc[(size_t)((r + 1) / R) * g.ldw + k] = betinv;
     }
   }
 }
@@ -193,13 +219,18 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
     if (upload2d(c, c->ddynoc, g.ldx, ddynoc, g.nx, g.ny)) return 1;
   }
   c->bd2oc.assign(bd2oc, bd2oc + g.nxt);
-  // pivot tables per mode: boc = bd2oc - rdm2oc(m)   (src/ocisubs.F:148-150)
-  std::vector<double> tab((size_t)g.wstride * g.nl, 0.0), boc(g.nk);
-  for (int m = 0; m < g.nl; ++m) {
-    for (int k = 0; k < g.nk; ++k) boc[k] = bd2oc[k] - c->prm.rdm2oc[m];
-    build_bet(g, c->prm.aoc, boc.data(), tab.data() + (size_t)g.wstride * m);
+  // Thomas diagonal + chunk-entry pivots per mode: boc = bd2oc - rdm2oc(m)   (src/ocisubs.F:148-150)
+  c->thR = thomas_rows_per_chunk(g.ny);
+  if (c->thR < 0) QG_FAIL("qgcm_hip_set_grid: nypo=%d exceeds the single-segment Thomas kernel (<= 2050)", g.ny);
+  {
+    std::vector<double> bocv((size_t)g.ldw * g.nl, 0.0), betc((size_t)g.ldw * TH_NC * g.nl, 0.0), boc(g.nk);
+    for (int m = 0; m < g.nl; ++m) {
+      for (int k = 0; k < g.nk; ++k) boc[k] = bd2oc[k] - c->prm.rdm2oc[m];
+      build_betc(g, c->thR, c->prm.aoc, boc.data(), bocv.data() + (size_t)g.ldw * m, betc.data() + (size_t)g.ldw * TH_NC * m);
+    }
+    HIPCHECK(hipMemcpy(c->boc, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(c->betc, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  HIPCHECK(hipMemcpy(c->bet, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   // FFT tables: complex length N = nxto (box DST-I of length nxto-1)
   const int N = g.nxt;
   c->fftN = N;
@@ -225,8 +256,6 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
-  const int nr = g.ny - 2;
-  if ((nr + TH_NC - 1) / TH_NC > 32) QG_FAIL("qgcm_hip_set_grid: nypo=%d exceeds the single-segment Thomas kernel (<= 2050)", g.ny);
   c->grid_set = true;
   return 0;
 }
@@ -381,23 +410,41 @@ extern "C" int qgcm_hip_get_inv_diag(qgcm_hip_handle c, double *xinhom, double *
 // ---------------------------------------------------------------------------
 // kernel launches
 // ---------------------------------------------------------------------------
+// Profiling mode: a HIP event pair brackets every kernel launch on the stream; the
+// pairs are drained once per step so the queue stays busy between kernels.
 struct KTimer {
   qgcm_hip_ctx *c;
-  int id;
-  KTimer(qgcm_hip_ctx *c_, int id_) : c(c_), id(id_) {
-    if (c->profiling) hipEventRecord(c->ev0, c->stream);
-  }
-  ~KTimer() {
+  size_t slot;
+  KTimer(qgcm_hip_ctx *c_, int id) : c(c_), slot(0) {
     if (c->profiling) {
-      hipEventRecord(c->ev1, c->stream);
-      hipEventSynchronize(c->ev1);
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, c->ev0, c->ev1);
-      c->kms[id] += ms;
-      c->klaunch[id] += 1;
+      slot = c->evkid.size();
+      if (c->evpool.size() < 2 * (slot + 1)) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        c->evpool.push_back(a);
+        c->evpool.push_back(b);
+      }
+      c->evkid.push_back(id);
+      (void)hipEventRecord(c->evpool[2 * slot], c->stream);
     }
   }
+  ~KTimer() {
+    if (c->profiling) (void)hipEventRecord(c->evpool[2 * slot + 1], c->stream);
+  }
 };
+
+static void drain_timers(qgcm_hip_ctx *c) {
+  if (c->evkid.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (size_t i = 0; i < c->evkid.size(); ++i) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->evpool[2 * i], c->evpool[2 * i + 1]);
+    c->kms[c->evkid[i]] += ms;
+    c->klaunch[c->evkid[i]] += 1;
+  }
+  c->evkid.clear();
+}
 
 static int launch_tend(qgcm_hip_ctx *c) {
   const QgGeom &g = c->g;
@@ -424,7 +471,8 @@ static int launch_tend(qgcm_hip_ctx *c) {
     P.ah4fac[k] = pr.ah4oc[k] / pr.fnot;
   }
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
-  dim3 grid((g.nx + TEND_TX - 1) / TEND_TX, (g.ny + TEND_TY - 1) / TEND_TY);
+  const int ntiles = ((g.nx + TEND_TX - 1) / TEND_TX) * ((g.ny + TEND_TY - 1) / TEND_TY);
+  dim3 grid(8 * ((ntiles + 7) / 8)); // 1-D: the kernel maps blockIdx -> tile per XCD band
   KTimer t(c, KN_TEND);
   switch (g.nl) {
     case 2: hipLaunchKernelGGL((k_tend<2, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
@@ -450,35 +498,45 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse) {
   for (int f = 0; f < c->nfac; ++f) P.fac[f] = c->fac[f];
   P.nlayers = nlayers;
   const int nrows = g.ny - 2;
-  dim3 grid((nrows + 1) / 2, nlayers);
+  const int npairs = (nrows + 1) / 2;
+  dim3 grid(npairs, nlayers);
+  dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF);
-  if (inverse) hipLaunchKernelGGL((k_dst_box<true>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
+  // wave-per-row-pair fast path when nxto = 64*M with an in-register M-point DFT available
+  if (c->fftN == 64 * 15 && !c->force_generic_dst) {
+    if (inverse) hipLaunchKernelGGL((k_dst64<15, true>), grid64, dim3(D64_NT), 0, c->stream, P);
+    else hipLaunchKernelGGL((k_dst64<15, false>), grid64, dim3(D64_NT), 0, c->stream, P);
+  } else if (c->fftN == 64 * 3 && !c->force_generic_dst) {
+    if (inverse) hipLaunchKernelGGL((k_dst64<3, true>), grid64, dim3(D64_NT), 0, c->stream, P);
+    else hipLaunchKernelGGL((k_dst64<3, false>), grid64, dim3(D64_NT), 0, c->stream, P);
+  } else if (inverse) hipLaunchKernelGGL((k_dst_box<true>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
   else hipLaunchKernelGGL((k_dst_box<false>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
   HIPCHECK(hipGetLastError());
   return 0;
 }
 
-static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *bet, int nlayers) {
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers) {
   const QgGeom &g = c->g;
   QgThomasParams P;
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.wrk = wrk;
-  P.bet = bet;
+  P.boc = boc;
+  P.betc = betc;
   P.aoc = c->prm.aoc;
   P.ftnorm = g.cyc ? 1.0 / g.nxt : 0.5 / g.nxt; // src/ocisubs.F:440, 547
   P.nlayers = nlayers;
-  const int nr = g.ny - 2;
-  const int need = (nr + TH_NC - 1) / TH_NC;
   dim3 grid((g.nk + TH_KW - 1) / TH_KW, nlayers);
   KTimer t(c, KN_THOMAS);
-  if (need <= 1) hipLaunchKernelGGL((k_thomas<1>), grid, dim3(TH_NT), 0, c->stream, P);
-  else if (need <= 2) hipLaunchKernelGGL((k_thomas<2>), grid, dim3(TH_NT), 0, c->stream, P);
-  else if (need <= 4) hipLaunchKernelGGL((k_thomas<4>), grid, dim3(TH_NT), 0, c->stream, P);
-  else if (need <= 8) hipLaunchKernelGGL((k_thomas<8>), grid, dim3(TH_NT), 0, c->stream, P);
-  else if (need <= 16) hipLaunchKernelGGL((k_thomas<16>), grid, dim3(TH_NT), 0, c->stream, P);
-  else if (need <= 32) hipLaunchKernelGGL((k_thomas<32>), grid, dim3(TH_NT), 0, c->stream, P);
-  else QG_FAIL("k_thomas: nypo too large for the single-segment kernel");
+  switch (c->thR) {
+    case 1: hipLaunchKernelGGL((k_thomas<1>), grid, dim3(TH_NT), 0, c->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_thomas<2>), grid, dim3(TH_NT), 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL((k_thomas<4>), grid, dim3(TH_NT), 0, c->stream, P); break;
+    case 8: hipLaunchKernelGGL((k_thomas<8>), grid, dim3(TH_NT), 0, c->stream, P); break;
+    case 16: hipLaunchKernelGGL((k_thomas<16>), grid, dim3(TH_NT), 0, c->stream, P); break;
+    case 32: hipLaunchKernelGGL((k_thomas<32>), grid, dim3(TH_NT), 0, c->stream, P); break;
+    default: QG_FAIL("k_thomas: nypo too large for the single-segment kernel");
+  }
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -508,7 +566,9 @@ static int launch_constr(qgcm_hip_ctx *c) {
   return 0;
 }
 
-static int launch_unpack(qgcm_hip_ctx *c) {
+static void fill_bdy_params(qgcm_hip_ctx *c, QgBdyParams &P);
+
+static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
   const QgGeom &g = c->g;
   QgUnpackParams P;
   memset(&P, 0, sizeof(P));
@@ -519,22 +579,27 @@ static int launch_unpack(qgcm_hip_ctx *c) {
   P.sc = c->sc;
   P.pch1 = c->pch1; P.pch2 = c->pch2; P.pbh = c->pbh;
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  QgBdyParams B;
+  fill_bdy_params(c, B); // B.qo = current qo; B.po unused by the fused kernel
   dim3 grid((g.nx + 255) / 256, g.ny);
   KTimer t(c, KN_UNPACK);
+#define QG_UNPACK(NLV)                                                                                   \
+  if (fuse_bdy) hipLaunchKernelGGL((k_unpack_box<NLV, true>), grid, dim3(256), 0, c->stream, P, B);      \
+  else hipLaunchKernelGGL((k_unpack_box<NLV, false>), grid, dim3(256), 0, c->stream, P, B)
   switch (g.nl) {
-    case 2: hipLaunchKernelGGL((k_unpack_box<2>), grid, dim3(256), 0, c->stream, P); break;
-    case 3: hipLaunchKernelGGL((k_unpack_box<3>), grid, dim3(256), 0, c->stream, P); break;
-    case 4: hipLaunchKernelGGL((k_unpack_box<4>), grid, dim3(256), 0, c->stream, P); break;
+    case 2: QG_UNPACK(2); break;
+    case 3: QG_UNPACK(3); break;
+    case 4: QG_UNPACK(4); break;
     default: QG_FAIL("k_unpack: unsupported nlo");
   }
+#undef QG_UNPACK
   HIPCHECK(hipGetLastError());
   return 0;
 }
 
-static int launch_ocqbdy(qgcm_hip_ctx *c) {
+static void fill_bdy_params(qgcm_hip_ctx *c, QgBdyParams &P) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
-  QgBdyParams P;
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.po = c->p[c->ip];
@@ -546,6 +611,12 @@ static int launch_ocqbdy(qgcm_hip_ctx *c) {
   P.beta = pr.beta;
   for (int k = 0; k < g.nl; ++k)
     for (int l = 0; l < g.nl; ++l) P.f0A[k + g.nl * l] = pr.fnot * pr.amatoc[k + g.nl * l];
+}
+
+static int launch_ocqbdy(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  QgBdyParams P;
+  fill_bdy_params(c, P);
   const int nmax = g.nx > g.ny ? g.nx : g.ny;
   dim3 grid((nmax + 255) / 256, g.cyc ? 2 : 4, g.nl);
   KTimer t(c, KN_OCQBDY);
@@ -577,17 +648,19 @@ extern "C" int qgcm_hip_qgostep(qgcm_hip_handle c) {
   return 0;
 }
 
-extern "C" int qgcm_hip_ocinvq(qgcm_hip_handle c) {
+static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
   if (check_ready(c, "qgcm_hip_ocinvq")) return 1;
   if (!c->homog_set) QG_FAIL("qgcm_hip_ocinvq: homogeneous solutions not set");
   if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
-  if (launch_thomas(c, c->wrk, c->bet, c->g.nl)) return 1;
+  if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl)) return 1;
   if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
   if (launch_constr(c)) return 1;
-  if (launch_unpack(c)) return 1;
+  if (launch_unpack(c, fuse_bdy)) return 1;
   c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
   return 0;
 }
+
+extern "C" int qgcm_hip_ocinvq(qgcm_hip_handle c) { return ocinvq_impl(c, false); }
 
 extern "C" int qgcm_hip_ocqbdy(qgcm_hip_handle c) {
   if (check_ready(c, "qgcm_hip_ocqbdy")) return 1;
@@ -601,10 +674,10 @@ extern "C" int qgcm_hip_lf_average(qgcm_hip_handle c) {
 
 static int one_step(qgcm_hip_ctx *c, int s) {
   if (qgcm_hip_qgostep(c)) return 1;
-  if (qgcm_hip_ocinvq(c)) return 1;
-  if (qgcm_hip_ocqbdy(c)) return 1;
+  if (ocinvq_impl(c, true)) return 1; // ocqbdy fused into the unpack kernel
   if ((s - 1) % 25 == 0)
     if (qgcm_hip_lf_average(c)) return 1;
+  if (c->profiling) drain_timers(c);
   return 0;
 }
 
@@ -661,14 +734,16 @@ extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *
   if (!wrk || !boc) QG_FAIL("qgcm_hip_helmholtz: null argument");
   const QgGeom &g = c->g;
   // pivots for this boc (box: boc(i-1) multiplies sine wavenumber i-1, src/ocisubs.F:470-478)
-  std::vector<double> tab((size_t)g.wstride, 0.0);
-  build_bet(g, c->prm.aoc, boc, tab.data());
-  HIPCHECK(hipMemcpyAsync(c->bet_tmp, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  std::vector<double> bocv((size_t)g.ldw, 0.0), betc((size_t)g.ldw * TH_NC, 0.0);
+  build_betc(g, c->thR, c->prm.aoc, boc, bocv.data(), betc.data());
+  HIPCHECK(hipMemcpyAsync(c->boc_tmp, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipMemcpyAsync(c->betc_tmp, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream)); // the staging vectors die at scope exit
   // interior columns i=2..nx-1 of every row -> wrk(c = i-2, j)
   HIPCHECK(hipMemcpy2DAsync(c->wrk, (size_t)g.ldw * 8, wrk + 1, (size_t)g.nx * 8, (size_t)(g.nx - 2) * 8, (size_t)g.ny,
                             hipMemcpyHostToDevice, c->stream));
   if (launch_dst(c, c->wrk, 1, false)) return 1;
-  if (launch_thomas(c, c->wrk, c->bet_tmp, 1)) return 1;
+  if (launch_thomas(c, c->wrk, c->boc_tmp, c->betc_tmp, 1)) return 1;
   if (launch_dst(c, c->wrk, 1, true)) return 1;
   HIPCHECK(hipMemcpy2DAsync(wrk + 1, (size_t)g.nx * 8, c->wrk, (size_t)g.ldw * 8, (size_t)(g.nx - 2) * 8, (size_t)g.ny,
                             hipMemcpyDeviceToHost, c->stream));
@@ -717,6 +792,7 @@ extern "C" int qgcm_hip_profile_steps(qgcm_hip_handle c, int s0, int n, double *
   HIPCHECK(hipStreamSynchronize(c->stream));
   c->profiling = true;
   int rc = qgcm_hip_steps(c, s0, n);
+  drain_timers(c);
   c->profiling = false;
   if (rc) return 1;
   for (int i = 0; i < KN_COUNT; ++i) {

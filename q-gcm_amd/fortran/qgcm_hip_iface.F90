@@ -1,0 +1,128 @@
+!-----------------------------------------------------------------------
+! qgcm_hip_iface - ISO_C_BINDING view of include/qgcm_hip.h
+!
+! One interface per C entry point; the derived type mirrors
+! struct qgcm_hip_params field for field (QGCM_HIP_MAXL = 8).
+!-----------------------------------------------------------------------
+module qgcm_hip_iface
+  use iso_c_binding
+  implicit none
+  public
+
+  integer, parameter :: QGCM_HIP_MAXL = 8
+
+  type, bind(C) :: qgcm_hip_params
+    integer(c_int) :: nxpo, nypo, nlo, cyclic
+    real(c_double) :: fnot, beta, dxo, dyo, tdto, delek, bccooc
+    real(c_double) :: ah2oc(QGCM_HIP_MAXL), ah4oc(QGCM_HIP_MAXL)
+    real(c_double) :: hoc(QGCM_HIP_MAXL), gpoc(QGCM_HIP_MAXL)
+    real(c_double) :: amatoc(QGCM_HIP_MAXL*QGCM_HIP_MAXL)
+    real(c_double) :: ctl2moc(QGCM_HIP_MAXL*QGCM_HIP_MAXL)
+    real(c_double) :: ctm2loc(QGCM_HIP_MAXL*QGCM_HIP_MAXL)
+    real(c_double) :: rdm2oc(QGCM_HIP_MAXL)
+    real(c_double) :: aoc
+  end type qgcm_hip_params
+
+  interface
+    integer(c_int) function qgcm_hip_create(h, prm, device) bind(C, name='qgcm_hip_create')
+      import :: c_ptr, c_int, qgcm_hip_params
+      type(c_ptr), intent(out) :: h
+      type(qgcm_hip_params), intent(in) :: prm
+      integer(c_int), value :: device
+    end function
+    integer(c_int) function qgcm_hip_destroy(h) bind(C, name='qgcm_hip_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    type(c_ptr) function qgcm_hip_last_error() bind(C, name='qgcm_hip_last_error')
+      import :: c_ptr
+    end function
+    integer(c_int) function qgcm_hip_set_grid(h, yporel, bd2oc, ddynoc) bind(C, name='qgcm_hip_set_grid')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: yporel(*), bd2oc(*), ddynoc(*)
+    end function
+    integer(c_int) function qgcm_hip_set_homog_box(h, ochom, cdiffo, cdhoc) bind(C, name='qgcm_hip_set_homog_box')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: ochom(*), cdiffo(*), cdhoc(*)
+    end function
+    integer(c_int) function qgcm_hip_set_state(h, po, pom, qo, qom) bind(C, name='qgcm_hip_set_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: po(*), pom(*), qo(*), qom(*)
+    end function
+    integer(c_int) function qgcm_hip_get_state(h, po, pom, qo, qom) bind(C, name='qgcm_hip_get_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: po(*), pom(*), qo(*), qom(*)
+    end function
+    integer(c_int) function qgcm_hip_set_forcing(h, wekpo, entoc, xon) bind(C, name='qgcm_hip_set_forcing')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: wekpo(*), entoc(*), xon(*)
+    end function
+    integer(c_int) function qgcm_hip_set_scalars(h, scal) bind(C, name='qgcm_hip_set_scalars')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: scal(*)
+    end function
+    integer(c_int) function qgcm_hip_get_scalars(h, scal) bind(C, name='qgcm_hip_get_scalars')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: scal(*)
+    end function
+    integer(c_int) function qgcm_hip_qgostep(h) bind(C, name='qgcm_hip_qgostep')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_ocinvq(h) bind(C, name='qgcm_hip_ocinvq')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_ocqbdy(h) bind(C, name='qgcm_hip_ocqbdy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_lf_average(h) bind(C, name='qgcm_hip_lf_average')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_steps(h, s0, n) bind(C, name='qgcm_hip_steps')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: s0, n
+    end function
+    integer(c_int) function qgcm_hip_sync(h) bind(C, name='qgcm_hip_sync')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_helmholtz(h, wrk, boc) bind(C, name='qgcm_hip_helmholtz')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(inout) :: wrk(*)
+      real(c_double), intent(in) :: boc(*)
+    end function
+  end interface
+
+contains
+
+  ! The reference's error convention is print + stop (e.g. src/ocisubs.F:361-365).
+  subroutine qgcm_hip_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    integer :: i
+    if (rc == 0) return
+    call c_f_pointer(qgcm_hip_last_error(), msg, [512])
+    print *, ' qgcm_hip error in ', where, ':'
+    do i = 1, 512
+      if (msg(i) == c_null_char) exit
+      write(*, '(a)', advance='no') msg(i)
+    enddo
+    print *
+    print *, ' program terminates'
+    stop 1
+  end subroutine qgcm_hip_check
+
+end module qgcm_hip_iface

@@ -1,0 +1,186 @@
+!-----------------------------------------------------------------------
+! Drop-in module procedures for the ocean hot path.
+!
+! The reference main program calls, once per ocean step and without
+! arguments (src/q-gcm.F:1243-1249):
+!
+!       call qgostep          (MODULE qgosubs, src/qgosubs.F:45)
+!       call ocinvq           (MODULE ocisubs, src/ocisubs.F:64)
+!       call ocqbdy (qo, po)  (MODULE vorsubs, src/vorsubs.F:245)
+!
+! and homsol calls hsbxoc (wrk, boc) at start-up (src/conhoms.F:572).
+! The modules below keep those names, argument lists and PUBLIC/PRIVATE
+! split, so q-gcm.F compiles against them unchanged; the bodies forward to
+! the C ABI of include/qgcm_hip.h.  Data still lives in the reference's own
+! state modules (parameters, occonst, ochomog, ocstate), which are USEd,
+! not replaced: the device copy is created from them on the first call
+! and refreshed/pulled with qgcm_hip_push / qgcm_hip_pull.
+!
+! Build with the same cpp macros as the reference (-Docean_only ...).
+!-----------------------------------------------------------------------
+module qgcm_hip_state
+  use iso_c_binding
+  use qgcm_hip_iface
+  implicit none
+  private
+  public :: qgcm_hip_handle, qgcm_hip_ensure, qgcm_hip_push, qgcm_hip_pull, &
+            qgcm_hip_push_forcing, qgcm_hip_shutdown, qgcm_hip_homog_ready
+
+  type(c_ptr), save :: qgcm_hip_handle = c_null_ptr
+  logical, save :: homog_sent = .false.
+
+contains
+
+  ! Create the device context from MODULE parameters / occonst / ocisubs data.
+  ! Safe to call repeatedly; homsol's first hsbxoc call triggers it.
+  subroutine qgcm_hip_ensure
+    use parameters
+    use occonst
+    use ocisubs_data, only : aoc, bd2oc
+    type(qgcm_hip_params) :: p
+    integer :: k, l
+    if (c_associated(qgcm_hip_handle)) return
+    p%nxpo = nxpo; p%nypo = nypo; p%nlo = nlo
+#ifdef cyclic_ocean
+    p%cyclic = 1
+#else
+    p%cyclic = 0
+#endif
+    p%fnot = fnot; p%beta = beta; p%dxo = dxo; p%dyo = dyo
+    p%tdto = tdto; p%delek = delek; p%bccooc = bccooc; p%aoc = aoc
+    p%ah2oc = 0.0d0; p%ah4oc = 0.0d0; p%hoc = 0.0d0; p%gpoc = 0.0d0
+    p%amatoc = 0.0d0; p%ctl2moc = 0.0d0; p%ctm2loc = 0.0d0; p%rdm2oc = 0.0d0
+    do k = 1, nlo
+      p%ah2oc(k) = ah2oc(k); p%ah4oc(k) = ah4oc(k); p%hoc(k) = hoc(k)
+      p%rdm2oc(k) = rdm2oc(k)
+      do l = 1, nlo
+        p%amatoc(k + nlo*(l-1)) = amatoc(k,l)
+        p%ctl2moc(k + nlo*(l-1)) = ctl2moc(k,l)
+        p%ctm2loc(k + nlo*(l-1)) = ctm2loc(k,l)
+      enddo
+    enddo
+    do k = 1, nlo-1
+      p%gpoc(k) = gpoc(k)
+    enddo
+    call qgcm_hip_check(qgcm_hip_create(qgcm_hip_handle, p, -1_c_int), 'qgcm_hip_create')
+    call qgcm_hip_check(qgcm_hip_set_grid(qgcm_hip_handle, yporel, bd2oc, ddynoc), 'qgcm_hip_set_grid')
+  end subroutine qgcm_hip_ensure
+
+  ! Send the homsol products once they exist (after "call homsol", src/q-gcm.F:976).
+  subroutine qgcm_hip_homog_ready
+    use ochomog
+    if (homog_sent) return
+    call qgcm_hip_ensure
+#ifndef cyclic_ocean
+    call qgcm_hip_check(qgcm_hip_set_homog_box(qgcm_hip_handle, ochom, cdiffo, cdhoc), 'qgcm_hip_set_homog_box')
+#endif
+    homog_sent = .true.
+  end subroutine qgcm_hip_homog_ready
+
+  ! host module arrays -> device (after initialisation / restart read / oml)
+  subroutine qgcm_hip_push
+    use parameters, only : nlo
+    use ocstate
+    use ochomog
+    real(c_double) :: scal(2*(nlo-1) + 4*nlo)
+    call qgcm_hip_homog_ready
+    call qgcm_hip_check(qgcm_hip_set_state(qgcm_hip_handle, po, pom, qo, qom), 'qgcm_hip_set_state')
+    scal = 0.0d0
+    scal(1:nlo-1) = dpioc
+    scal(nlo:2*(nlo-1)) = dpiocp
+    call qgcm_hip_check(qgcm_hip_set_scalars(qgcm_hip_handle, scal), 'qgcm_hip_set_scalars')
+    call qgcm_hip_push_forcing
+  end subroutine qgcm_hip_push
+
+  subroutine qgcm_hip_push_forcing
+    use ocstate, only : wekpo, entoc
+    use ochomog, only : xon
+    call qgcm_hip_check(qgcm_hip_set_forcing(qgcm_hip_handle, wekpo, entoc, xon), 'qgcm_hip_set_forcing')
+  end subroutine qgcm_hip_push_forcing
+
+  ! device -> host module arrays (before valids, prsamp, monnc_comp, resave, ocnc_out ...)
+  subroutine qgcm_hip_pull
+    use parameters, only : nlo
+    use ocstate
+    use ochomog
+    real(c_double) :: scal(2*(nlo-1) + 4*nlo)
+    call qgcm_hip_check(qgcm_hip_get_state(qgcm_hip_handle, po, pom, qo, qom), 'qgcm_hip_get_state')
+    call qgcm_hip_check(qgcm_hip_get_scalars(qgcm_hip_handle, scal), 'qgcm_hip_get_scalars')
+    dpioc = scal(1:nlo-1)
+    dpiocp = scal(nlo:2*(nlo-1))
+  end subroutine qgcm_hip_pull
+
+  subroutine qgcm_hip_shutdown
+    if (c_associated(qgcm_hip_handle)) then
+      call qgcm_hip_check(qgcm_hip_destroy(qgcm_hip_handle), 'qgcm_hip_destroy')
+      qgcm_hip_handle = c_null_ptr
+    endif
+  end subroutine qgcm_hip_shutdown
+
+end module qgcm_hip_state
+
+!-----------------------------------------------------------------------
+module qgosubs
+  ! same public surface as src/qgosubs.F:23-39 (qgostep PUBLIC; ocadif is gone:
+  ! it is fused into the tendency kernel)
+  implicit none
+  private
+  public :: qgostep
+contains
+  subroutine qgostep
+    use qgcm_hip_iface
+    use qgcm_hip_state
+    call qgcm_hip_check(qgcm_hip_qgostep(qgcm_hip_handle), 'qgostep')
+  end subroutine qgostep
+end module qgosubs
+
+!-----------------------------------------------------------------------
+module ocisubs
+  ! same public surface as src/ocisubs.F:23-55: ocinvq, hsbxoc (box) and the
+  ! module data lwftoc/oftwrk/aoc/bd2oc, re-exported from ocisubs_data so that
+  ! the reference main program's "USE ocisubs" keeps working.
+  use ocisubs_data
+  implicit none
+  private
+  public :: ocinvq, lwftoc, oftwrk, aoc, bd2oc
+#ifndef cyclic_ocean
+  public :: hsbxoc
+#endif
+contains
+  subroutine ocinvq
+    use qgcm_hip_iface
+    use qgcm_hip_state
+    call qgcm_hip_check(qgcm_hip_ocinvq(qgcm_hip_handle), 'ocinvq')
+  end subroutine ocinvq
+
+#ifndef cyclic_ocean
+  subroutine hsbxoc (wrk, boc)
+    use parameters, only : nxpo, nypo, nxto
+    use qgcm_hip_iface
+    use qgcm_hip_state
+    double precision, intent(inout) :: wrk(nxpo,nypo)
+    double precision, intent(in) :: boc(nxto)
+    call qgcm_hip_ensure
+    call qgcm_hip_check(qgcm_hip_helmholtz(qgcm_hip_handle, wrk, boc), 'hsbxoc')
+  end subroutine hsbxoc
+#endif
+end module ocisubs
+
+!-----------------------------------------------------------------------
+module vorsubs_hip
+  ! ocqbdy of src/vorsubs.F:245-388.  qcomp / merqcy (init only) stay in the
+  ! reference's vorsubs; link this module's ocqbdy in their place for the
+  ! per-step call.  The arguments are the module arrays themselves
+  ! ("call ocqbdy (qo, po)", src/q-gcm.F:1249); the device owns the data.
+  implicit none
+  private
+  public :: ocqbdy
+contains
+  subroutine ocqbdy (qo, po)
+    use parameters, only : nxpo, nypo, nlo
+    use qgcm_hip_iface
+    use qgcm_hip_state
+    double precision :: qo(nxpo,nypo,nlo), po(nxpo,nypo,nlo)
+    call qgcm_hip_check(qgcm_hip_ocqbdy(qgcm_hip_handle), 'ocqbdy')
+  end subroutine ocqbdy
+end module vorsubs_hip

@@ -95,6 +95,9 @@ PRESETS = {
     "box_tiny2": OceanConfig("box_tiny2", 8, 8, 5, 4, 6, 2, fnot=5.92e-05, beta=2.08e-11, cyclic=False,
                              dxo=1.0e5, dta=720.0, ah2oc=(0.0, 0.0), ah4oc=(3.2e12, 3.2e12),
                              hoc=(500.0, 3500.0), gpoc=(0.02,)),
+    # nxto = 192 = 64*3: exercises the wave-per-row-pair DST kernel at a size the oracle runs in seconds
+    "box_med": OceanConfig("box_med", 16, 10, 12, 6, 16, 3, dxo=2.5e4, dta=240.0,
+                           ah4oc=(1.2e10,) * 3, **_NATL),
     "cyc_tiny": OceanConfig("cyc_tiny", 4, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
                             ah4oc=(3.2e12,) * 3, **_SOCN),
     "cyc_small": OceanConfig("cyc_small", 6, 10, 6, 4, 16, 3, dxo=5.0e4, dta=360.0,

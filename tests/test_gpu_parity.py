@@ -145,6 +145,46 @@ def test_random_state_vs_oracle(case):
         o.close()
 
 
+def test_fast_dst_grid_vs_oracle():
+    """box_med has nxto = 192 = 64*3 and therefore runs the wave-per-row-pair DST
+    kernel (k_dst64); check the solver and whole steps against the CPU oracle, and
+    the generic Stockham kernel against the fast one."""
+    import os
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("box_med")
+    o = make_oracle(cfg)
+    m = OceanModel(cfg)
+    os.environ["QGCM_HIP_GENERIC_DST"] = "1"
+    try:
+        mg = OceanModel(cfg)
+    finally:
+        del os.environ["QGCM_HIP_GENERIC_DST"]
+    try:
+        rng = np.random.default_rng(21)
+        rhs = np.asfortranarray(rng.standard_normal((cfg.nxpo, cfg.nypo)))
+        for mode in range(cfg.nlo):
+            boc = m.bd2oc - m.rdm2oc[mode]
+            ref = o.helmholtz(rhs, boc)
+            assert relerr(m.helmholtz(rhs, boc), ref) < TOL_CALL
+            assert relerr(mg.helmholtz(rhs, boc), ref) < TOL_CALL
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        for mod in (m, mg, o):
+            mod.set_p(po, 0.99 * po)
+            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+        m.steps(30, s0=1)
+        mg.steps(30, s0=1)
+        o.steps(1, 30)
+        for f, x, y, z in zip(FIELDS, m.get_state(), mg.get_state(), o.get_state()):
+            assert relerr(x, z) < 1e-11, f
+            assert relerr(y, z) < 1e-11, f
+    finally:
+        m.close()
+        mg.close()
+        o.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json full size (NAtl 5 km, 961 x 961 x 3)
 # ---------------------------------------------------------------------------
