@@ -21,6 +21,10 @@
 #include "qgcm_dev.h"
 #include "k_dst.h" // cplx helpers
 
+// The row transform is not required to be bitwise FFTPACK:
+// let the compiler fuse multiply-adds in this file only.
+#pragma clang fp contract(fast)
+
 #define D64_WAVES 4
 #define D64_NT (64 * D64_WAVES)
 #define D64_ROW 72 // padded length of one 64-point row (pad 1 per 8)
@@ -148,11 +152,12 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   // Everything this lane will need from global tables is requested up front so
   // that it arrives together with the rows: W_N^(lane*k1), the dsint sine
   // factors, and this wave's copy of the 64-point twiddles.
-  cplx tw1[M];
+  cplx tw1[M]; // W_N^(lane*k1) as powers of W_N^lane (one coalesced load; depth-4 product tree)
+  {
+    double2 w = P.twid[lane];
+    tw1[1 % M] = {w.x, w.y};
 #pragma unroll
-  for (int k1 = 1; k1 < M; ++k1) {
-    double2 w = P.twid[lane * k1];
-    tw1[k1] = {w.x, w.y};
+    for (int k1 = 2; k1 < M; ++k1) tw1[k1] = cmul(tw1[k1 / 2], tw1[k1 - k1 / 2]);
   }
   double snv[M];
 #pragma unroll
@@ -252,20 +257,23 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
 
   // ---- (3) split + FFTPACK post-process (dsint.f:37-44) ----------------------
   // Z[k], k = k1 + M*k2, k2 = c + 8d, lives at F[k1*72 + 9c + d]
-  auto zidx = [](int k) {
-    int k1 = k % M, k2 = k / M;
-    return k1 * D64_ROW + 9 * (k2 & 7) + (k2 >> 3);
-  };
   constexpr int K = NS2;              // odd outputs b[2k+1], k = 1..K
   constexpr int CH = (K + 63) / 64;   // k's per lane
   const int k0 = 1 + lane * CH;
+  // (k1, k2) of k0 and of N-k0 once; then step k -> k+1 / N-k -> N-k-1 without divisions
+  int ak1 = k0 % M, ak2 = k0 / M;
+  int bk1 = (N - k0) % M, bk2 = (N - k0) / M;
   double rea[CH], ima[CH], reb[CH], imb[CH];
   double suma = 0.0, sumb = 0.0;
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
     const int k = k0 + t;
+    const int za = ak1 * D64_ROW + 9 * (ak2 & 7) + (ak2 >> 3);
+    const int zb = bk1 * D64_ROW + 9 * (bk2 & 7) + (bk2 >> 3);
+    if (++ak1 == M) { ak1 = 0; ++ak2; }
+    if (--bk1 < 0) { bk1 = M - 1; --bk2; }
     if (k <= K) {
-      cplx z1 = F[zidx(k)], z2 = F[zidx(N - k)];
+      cplx z1 = F[za], z2 = F[zb];
       rea[t] = 0.5 * (z1.x + z2.x);
       ima[t] = 0.5 * (z1.y - z2.y);
       reb[t] = 0.5 * (z1.y + z2.y);
@@ -290,12 +298,16 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   const double b1a = 0.5 * z0.x, b1b = 0.5 * z0.y;
   double runa = b1a + (inca - suma), runb = b1b + (incb - sumb);
   wave_lds_sync(); // all spectrum reads done: reuse the buffer for the output rows
+  // Output staging: element i of a row lives at i + (i >> 4) (one pad per 16) so that
+  // the per-lane runs of 16 consecutive outputs fall on distinct LDS banks.
+  constexpr int NP = N + N / 16; // padded row length
+  auto pidx = [](int i) { return i + (i >> 4); };
   double rsa = 0.0, rsb = 0.0;
   if (lane == 0) {
     raw[0] = b1a;
-    raw[N] = b1b;
-    raw[N - 1] = 0.0; // padding slots (element n of each row is unused)
-    raw[2 * N - 1] = 0.0;
+    raw[NP] = b1b;
+    raw[pidx(N - 1)] = 0.0; // padding slots (element n of each row is unused)
+    raw[NP + pidx(N - 1)] = 0.0;
     rsa = b1a;
     rsb = b1b;
   }
@@ -305,10 +317,10 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
     if (k <= K) {
       runa += rea[t];
       runb += reb[t];
-      raw[2 * k - 1] = -ima[t];
-      raw[2 * k] = runa;
-      raw[N + 2 * k - 1] = -imb[t];
-      raw[N + 2 * k] = runb;
+      raw[pidx(2 * k - 1)] = -ima[t];
+      raw[pidx(2 * k)] = runa;
+      raw[NP + pidx(2 * k - 1)] = -imb[t];
+      raw[NP + pidx(2 * k)] = runb;
       rsa += runa - ima[t];
       rsb += runb - imb[t];
     }
@@ -317,14 +329,13 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   {
     double2 *ga = reinterpret_cast<double2 *>(rowa);
     double2 *gb = reinterpret_cast<double2 *>(rowb);
-    const double2 *ra = reinterpret_cast<const double2 *>(raw);
-    const double2 *rb = reinterpret_cast<const double2 *>(raw + N);
 #pragma unroll
     for (int u = 0; u < (N / 2 + 63) / 64; ++u) {
       int t = lane + 64 * u;
       if (t < N / 2) {
-        ga[t] = ra[t];
-        if (has_b) gb[t] = rb[t];
+        const int i = pidx(2 * t); // 2t and 2t+1 share a 16-group: consecutive after padding
+        ga[t] = double2{raw[i], raw[i + 1]};
+        if (has_b) gb[t] = double2{raw[NP + i], raw[NP + i + 1]};
       }
     }
   }
@@ -340,3 +351,6 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
     }
   }
 }
+
+// back to the library default (-ffp-contract=off) for everything included after this file
+#pragma clang fp contract(off)

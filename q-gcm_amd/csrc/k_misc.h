@@ -40,71 +40,105 @@ __device__ inline double qg_block_sum(double v, double *red, int tid) {
   return r;
 }
 
-__global__ __launch_bounds__(CS_NT) void k_constr_box(const QgConstrParams P) {
-  __shared__ double red[QG_MAXL][CS_NT];
-  __shared__ double xin[QG_MAXL];
-  const int tid = threadIdx.x;
-  const int nl = P.g.nl, ny = P.g.ny;
-  // all modes at once: independent loads first, then one fixed-order tree per mode
-  double s[QG_MAXL];
-  for (int m = 0; m < nl; ++m) {
-    double acc = 0.0;
-    for (int j = 1 + tid; j <= ny - 2; j += CS_NT) acc += P.rowsum[(long)m * ny + j];
-    s[m] = acc;
+// One wavefront; NL is a template parameter so that every small array lives in
+// registers (run-time indexed locals would go to scratch memory and turn this
+// latency-bound kernel several times slower).
+template <int NL>
+__global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
+  const int lane = threadIdx.x;
+  const int ny = P.g.ny;
+  constexpr int n1 = NL - 1;
+  double s[NL];
+#pragma unroll
+  for (int m = 0; m < NL; ++m) s[m] = 0.0;
+  for (int j = 1 + lane; j <= ny - 2; j += 64) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
   }
-  for (int m = 0; m < nl; ++m) red[m][tid] = s[m];
-  __syncthreads();
-  for (int off = CS_NT / 2; off > 0; off >>= 1) {
-    if (tid < off)
-      for (int m = 0; m < nl; ++m) red[m][tid] += red[m][tid + off];
-    __syncthreads();
+  // fixed-order butterfly: every lane ends with the same total
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
   }
-  if (tid < nl) xin[tid] = red[tid][0] * P.dxo * P.dyo;
-  __syncthreads();
-  if (tid == 0) {
-    QgScalars *sc = P.sc;
-    const int n1 = nl - 1;
-    double rhs[QG_MAXL], x[QG_MAXL], r[QG_MAXL], w[QG_MAXL];
-    for (int m = 0; m < nl; ++m) sc->xinhom[m] = xin[m];
+  if (lane != 0) return;
+  QgScalars *sc = P.sc;
+  double xin[NL], rhs[n1], x[n1], r[n1], w[n1];
+#pragma unroll
+  for (int m = 0; m < NL; ++m) {
+    xin[m] = s[m] * P.dxo * P.dyo;
+    sc->xinhom[m] = xin[m];
+  }
+#pragma unroll
+  for (int k = 0; k < n1; ++k) {
+    double aient = (k == 0) ? sc->xon[0] : 0.0;
+    double aitmp = sc->dpioc[k];
+    double dpn = sc->dpiocp[k] - P.tdto * P.gpoc[k] * aient; // src/ocisubs.F:343-345
+    sc->dpioc[k] = dpn;
+    sc->dpiocp[k] = aitmp;
+    double rhsum = 0.0;
+#pragma unroll
+    for (int m = 0; m < NL; ++m) rhsum = rhsum + P.cs.cdiffo[m + NL * k] * xin[m];
+    rhs[k] = dpn - rhsum;
+    x[k] = rhs[k];
+  }
+  // LU solve (DGETRS) with the host-side factors; pivots applied as selects
+  auto lu_solve = [&](double *b) {
+#pragma unroll
     for (int k = 0; k < n1; ++k) {
-      double aient = (k == 0) ? sc->xon[0] : 0.0;
-      double aitmp = sc->dpioc[k];
-      sc->dpioc[k] = sc->dpiocp[k] - P.tdto * P.gpoc[k] * aient;
-      sc->dpiocp[k] = aitmp;
-      double rhsum = 0.0;
-      for (int m = 0; m < nl; ++m) rhsum = rhsum + P.cs.cdiffo[m + nl * k] * xin[m];
-      rhs[k] = sc->dpioc[k] - rhsum;
-      x[k] = rhs[k];
-    }
-    qg_lu_solve(n1, P.cs.cdhlu, P.cs.ipiv, x);
-    // iterative refinement with DGERFS's stopping rule (ITMAX = 5)
-    const double eps = 1.1102230246251565e-16, safmin = 2.2250738585072014e-308;
-    const double safe1 = (n1 + 1) * safmin, safe2 = safe1 / eps;
-    double lstres = 3.0;
-    for (int count = 1;; ++count) {
-      for (int i = 0; i < n1; ++i) {
-        double s = rhs[i], t = fabs(rhs[i]);
-        for (int j = 0; j < n1; ++j) {
-          s -= P.cs.cdhoc[i + n1 * j] * x[j];
-          t += fabs(P.cs.cdhoc[i + n1 * j]) * fabs(x[j]);
+      const int pk = P.cs.ipiv[k];
+#pragma unroll
+      for (int i = 0; i < n1; ++i)
+        if (i > k && i == pk) {
+          double t = b[k];
+          b[k] = b[i];
+          b[i] = t;
         }
-        r[i] = s;
-        w[i] = t;
-      }
-      double berr = 0.0;
-      for (int i = 0; i < n1; ++i) {
-        double v = (w[i] > safe2) ? fabs(r[i]) / w[i] : (fabs(r[i]) + safe1) / (w[i] + safe1);
-        if (v > berr) berr = v;
-      }
-      if (berr > eps && 2.0 * berr <= lstres && count <= 5) {
-        qg_lu_solve(n1, P.cs.cdhlu, P.cs.ipiv, r);
-        for (int i = 0; i < n1; ++i) x[i] += r[i];
-        lstres = berr;
-      } else
-        break;
     }
-    for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
+#pragma unroll
+    for (int k = 0; k < n1; ++k)
+#pragma unroll
+      for (int i = k + 1; i < n1; ++i) b[i] -= P.cs.cdhlu[i + n1 * k] * b[k];
+#pragma unroll
+    for (int k = n1 - 1; k >= 0; --k) {
+      b[k] /= P.cs.cdhlu[k + n1 * k];
+#pragma unroll
+      for (int i = 0; i < k; ++i) b[i] -= P.cs.cdhlu[i + n1 * k] * b[k];
+    }
+  };
+  lu_solve(x);
+  // iterative refinement with DGERFS's stopping rule (ITMAX = 5)
+  const double eps = 1.1102230246251565e-16, safmin = 2.2250738585072014e-308;
+  const double safe1 = (n1 + 1) * safmin, safe2 = safe1 / eps;
+  double lstres = 3.0;
+  for (int count = 1;; ++count) {
+#pragma unroll
+    for (int i = 0; i < n1; ++i) {
+      double sv = rhs[i], t = fabs(rhs[i]);
+#pragma unroll
+      for (int j = 0; j < n1; ++j) {
+        sv -= P.cs.cdhoc[i + n1 * j] * x[j];
+        t += fabs(P.cs.cdhoc[i + n1 * j]) * fabs(x[j]);
+      }
+      r[i] = sv;
+      w[i] = t;
+    }
+    double berr = 0.0;
+#pragma unroll
+    for (int i = 0; i < n1; ++i) {
+      double v = (w[i] > safe2) ? fabs(r[i]) / w[i] : (fabs(r[i]) + safe1) / (w[i] + safe1);
+      if (v > berr) berr = v;
+    }
+    if (berr > eps && 2.0 * berr <= lstres && count <= 5) {
+      lu_solve(r);
+#pragma unroll
+      for (int i = 0; i < n1; ++i) x[i] += r[i];
+      lstres = berr;
+    } else
+      break;
   }
+#pragma unroll
+  for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
 }
 
 // ---------------------------------------------------------------------------

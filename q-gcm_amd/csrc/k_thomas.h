@@ -26,6 +26,7 @@
 #define TH_KW 16   // wavenumbers per workgroup (128-B line)
 #define TH_NC 64   // chunks per column
 #define TH_NT (TH_KW * TH_NC)
+static_assert(TH_NC == 64 && TH_KW == 16, "the chunk scan maps 64 chunks to the lanes of 16 waves");
 
 // grid: (ceil(nk/16), nlayers)
 template <int R>
@@ -78,12 +79,23 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   sC[c][kk] = C;
   sD[c][kk] = D;
   __syncthreads();
-  if (tid < TH_KW) {
-    double u = 0.0;
-    for (int cc = 0; cc < TH_NC; ++cc) {
-      sIn[cc][tid] = u;
-      u = sC[cc][tid] + sD[cc][tid] * u;
+  // Compose the 64 chunk maps of one wavenumber with a wave scan: wave w takes
+  // wavenumber kk = w, lane = chunk.  After the inclusive scan Cs is the value
+  // leaving each chunk (the inflow to chunk 0 is zero), so the inflow of chunk c
+  // is the scanned value of chunk c-1.
+  const int lane = tid & 63, wv = tid >> 6;
+  {
+    double Cs = sC[lane][wv], Ds = sD[lane][wv];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      double Cp = __shfl_up(Cs, off), Dp = __shfl_up(Ds, off);
+      if (lane >= off) {
+        Cs = Cs + Ds * Cp;
+        Ds = Ds * Dp;
+      }
     }
+    double inflow = __shfl_up(Cs, 1);
+    sIn[lane][wv] = (lane == 0) ? 0.0 : inflow;
   }
   __syncthreads();
   double u = sIn[c][kk];
@@ -99,12 +111,20 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __syncthreads();
   sC[c][kk] = C; // D is the same product as in the forward sweep
   __syncthreads();
-  if (tid < TH_KW) {
-    double v = 0.0;
-    for (int cc = TH_NC - 1; cc >= 0; --cc) {
-      sIn[cc][tid] = v;
-      v = sC[cc][tid] + sD[cc][tid] * v;
+  {
+    // same scan in the opposite direction: lane l stands for chunk 63-l
+    const int cr = 63 - lane;
+    double Cs = sC[cr][wv], Ds = sD[cr][wv];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      double Cp = __shfl_up(Cs, off), Dp = __shfl_up(Ds, off);
+      if (lane >= off) {
+        Cs = Cs + Ds * Cp;
+        Ds = Ds * Dp;
+      }
     }
+    double inflow = __shfl_up(Cs, 1);
+    sIn[cr][wv] = (lane == 0) ? 0.0 : inflow;
   }
   __syncthreads();
   double v = sIn[c][kk];

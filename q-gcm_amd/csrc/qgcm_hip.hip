@@ -561,7 +561,12 @@ static int launch_constr(qgcm_hip_ctx *c) {
     P.ctm2l[i] = pr.ctm2loc[i];
   }
   KTimer t(c, KN_CONSTR);
-  hipLaunchKernelGGL(k_constr_box, dim3(1), dim3(CS_NT), 0, c->stream, P);
+  switch (g.nl) {
+    case 2: hipLaunchKernelGGL((k_constr_box<2>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 3: hipLaunchKernelGGL((k_constr_box<3>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL((k_constr_box<4>), dim3(1), dim3(64), 0, c->stream, P); break;
+    default: QG_FAIL("k_constr: unsupported nlo");
+  }
   HIPCHECK(hipGetLastError());
   return 0;
 }
