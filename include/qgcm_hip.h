@@ -63,6 +63,12 @@ typedef struct qgcm_hip_params {
   double ctm2loc[QGCM_HIP_MAXL * QGCM_HIP_MAXL];     /* ctm2loc(nlo,nlo) */
   double rdm2oc[QGCM_HIP_MAXL];                      /* 1/Rd^2 per mode */
   double aoc;                                        /* ocisubs: 1/dyo^2 (q-gcm.F:932) */
+  /* y-slab decomposition (no counterpart in the reference, which is single-process):
+   * this handle owns the global rows slab_g0..slab_g1 (1-based, inclusive) of the
+   * nypo rows; 0,0 = the whole domain.  In slab mode every host array passed to
+   * set_/get_* is the LOCAL block (nxpo, nyl, .) with nyl = owned rows + a 3-row
+   * halo on each side that has a neighbour (qgcm_hip_local_rows). */
+  int slab_g0, slab_g1;
 } qgcm_hip_params;
 
 /* ---- life cycle -------------------------------------------------------- */
@@ -125,6 +131,31 @@ int qgcm_hip_sync(qgcm_hip_handle h);
 /* Helmholtz solve for homsol: wrk(nxpo,nypo) in/out, boc(nxto)
  * (replaces hsbxoc / hscyoc, src/ocisubs.F:415-618). Synchronous. */
 int qgcm_hip_helmholtz(qgcm_hip_handle h, double *wrk, const double *boc);
+
+/* ---- y-slab building blocks (multi-GPU; one handle per slab) -------------
+ * A distributed step is: qgostep | row_transform(0) | thomas_phase 1, exchange,
+ * 2, exchange, 3 | row_transform(1) | xin_partial, exchange | constr_partials |
+ * unpack | halo_pack, exchange, halo_unpack.  All buffers named *_dev are DEVICE
+ * pointers owned by the caller (e.g. torch tensors used with torch.distributed);
+ * every call is asynchronous on the handle's stream. */
+int qgcm_hip_local_rows(qgcm_hip_handle h, int *nyl, int *joff, int *jlo, int *jhi);
+int qgcm_hip_row_transform(qgcm_hip_handle h, int inverse);
+/* number of doubles of one Thomas summary message: 2 * nlo * ldw */
+int qgcm_hip_thomas_msg_len(qgcm_hip_handle h);
+/* phase 1: slab forward map -> send_dev.  phase 2: gath_dev = all ranks' phase-1
+ * messages (rank-major) -> forward sweep, slab backward map -> send_dev.
+ * phase 3: gath_dev = all ranks' phase-2 messages -> backward sweep. */
+int qgcm_hip_thomas_phase(qgcm_hip_handle h, int phase, const double *gath_dev, double *send_dev,
+                          int rank, int nranks);
+/* local area-integral partials xin(nlo) -> send_dev (nlo doubles) */
+int qgcm_hip_xin_partial(qgcm_hip_handle h, double *send_dev);
+/* gath_dev = all ranks' partials (rank-major, nlo each): sum in rank order + mass-constraint solve */
+int qgcm_hip_constr_partials(qgcm_hip_handle h, const double *gath_dev, int nranks);
+int qgcm_hip_unpack(qgcm_hip_handle h, int fuse_ocqbdy);
+/* halo messages: (3 rows of po + 1 row of qo) * nlo rows of ldx doubles each */
+int qgcm_hip_halo_msg_len(qgcm_hip_handle h);
+int qgcm_hip_halo_pack(qgcm_hip_handle h, double *to_lower_dev, double *to_upper_dev);
+int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const double *from_upper_dev);
 
 /* ---- measurement -------------------------------------------------------- */
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of

@@ -103,7 +103,7 @@ __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict_
   }
 }
 
-// grid: (ceil(nrows/2), nlayers);  rows j = 2..ny-1  (nrows = ny-2)
+// grid: (ceil(nrows/2), nlayers);  rows j = jr0..jr1 (owned, interior to the global domain)
 // dynamic LDS: 2*N cplx + 2*DST_NT doubles
 template <bool ROWSUM>
 __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y;
-  const int ja = 2 + 2 * blockIdx.x; // first row (1-based j)
-  const bool has_b = (ja + 1 <= ny - 1);
+  const int ja = P.g.jr0 + 2 * blockIdx.x; // first row (1-based local j)
+  const bool has_b = (ja + 1 <= P.g.jr1);
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
   double *rowb = rowa + ldw;
 

@@ -141,9 +141,9 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y;
   const int pair = blockIdx.x * D64_WAVES + wv;
-  const int ja = 2 + 2 * pair;
-  if (ja > ny - 1) return; // whole wave leaves; no workgroup barrier is ever used
-  const bool has_b = (ja + 1 <= ny - 1);
+  const int ja = P.g.jr0 + 2 * pair;
+  if (ja > P.g.jr1) return; // whole wave leaves; no workgroup barrier is ever used
+  const bool has_b = (ja + 1 <= P.g.jr1);
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
   double *rowb = rowa + ldw;
   cplx *F = Fsh[wv];

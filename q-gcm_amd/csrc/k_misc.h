@@ -51,15 +51,23 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
   double s[NL];
 #pragma unroll
   for (int m = 0; m < NL; ++m) s[m] = 0.0;
-  for (int j = 1 + lane; j <= ny - 2; j += 64) {
+  if (P.npart > 0) {
+    // y-slab run: the per-rank partial sums were all-gathered; add them in rank order
+    for (int r = 0; r < P.npart; ++r) {
 #pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
-  }
-  // fixed-order butterfly: every lane ends with the same total
+      for (int m = 0; m < NL; ++m) s[m] += P.partials[r * NL + m];
+    }
+  } else {
+    for (int j = P.g.jr0 - 1 + lane; j <= P.g.jr1 - 1; j += 64) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+      for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
+    }
+    // fixed-order butterfly: every lane ends with the same total
 #pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
+    }
   }
   if (lane != 0) return;
   QgScalars *sc = P.sc;
@@ -141,6 +149,29 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
   for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
 }
 
+// y-slab run: this rank's share of the area integrals (row sums of its own rows)
+template <int NL>
+__global__ __launch_bounds__(64) void k_xin_partial(const QgConstrParams P, double *out) {
+  const int lane = threadIdx.x;
+  const int ny = P.g.ny;
+  double s[NL];
+#pragma unroll
+  for (int m = 0; m < NL; ++m) s[m] = 0.0;
+  for (int j = P.g.jr0 - 1 + lane; j <= P.g.jr1 - 1; j += 64) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) out[m] = s[m];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K7: add homogeneous solutions, modes -> layers (src/ocisubs.F:377-401).
 // The reference also copies po -> pom here; the p buffers rotate instead, so
@@ -149,9 +180,10 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
 // ---------------------------------------------------------------------------
 template <int NL>
 __device__ __forceinline__ void unpack_point(const QgUnpackParams &P, int gi, int gj, double *pl) {
-  const int nx = P.g.nx, ny = P.g.ny;
+  const int nx = P.g.nx;
   const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
-  const bool inner = (gi >= 2 && gi <= nx - 1 && gj >= 2 && gj <= ny - 1);
+  const int G = gj + P.g.joff; // global row
+  const bool inner = (gi >= 2 && gi <= nx - 1 && G >= 2 && G <= P.g.nyg - 1);
   const long ow = (long)(gj - 1) * P.g.ldw + (gi - 2);
   double pm[NL];
   pm[0] = inner ? P.wrk[ow] : 0.0;
@@ -174,21 +206,22 @@ __device__ __forceinline__ void unpack_point(const QgUnpackParams &P, int gi, in
 // a launch; the stand-alone entry points keep unpack and ocqbdy separate.
 template <int NL, bool BDY>
 __global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P, const QgBdyParams B) {
-  const int nx = P.g.nx, ny = P.g.ny;
+  const int nx = P.g.nx;
   const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  const int gj = blockIdx.y + 1;
-  if (gi > nx || gj > ny) return;
+  const int gj = P.g.jlo + blockIdx.y; // owned local row
+  if (gi > nx || gj > P.g.jhi) return;
+  const int G = gj + P.g.joff, nyg = P.g.nyg;
   const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
   double pl[NL];
   unpack_point<NL>(P, gi, gj, pl);
 #pragma unroll
   for (int k = 0; k < NL; ++k) P.pnew[P.g.fstride * k + o] = pl[k];
   if (BDY) {
-    const bool ns = (gj == 1 || gj == ny);
+    const bool ns = (G == 1 || G == nyg);
     const bool we = (gi == 1 || gi == nx);
     if (ns || we) {
       const int ii = ns ? gi : (gi == 1 ? 2 : nx - 1);
-      const int jj = ns ? (gj == 1 ? 2 : ny - 1) : gj;
+      const int jj = ns ? (G == 1 ? gj + 1 : gj - 1) : gj;
       double pin[NL];
       unpack_point<NL>(P, ii, jj, pin);
       const double by = B.beta * B.yporel[gj - 1];
@@ -220,11 +253,15 @@ __global__ __launch_bounds__(256) void k_ocqbdy(const QgBdyParams P) {
   if (side < 2) {
     if (t > nx) return;
     gi = t; ii = t;
-    gj = (side == 0) ? 1 : ny;
-    jj = (side == 0) ? 2 : ny - 1;
+    // only the rank that owns the global boundary row does it
+    if (side == 0 && P.g.jlo + P.g.joff != 1) return;
+    if (side == 1 && P.g.jhi + P.g.joff != P.g.nyg) return;
+    gj = (side == 0) ? P.g.jlo : P.g.jhi;
+    jj = (side == 0) ? gj + 1 : gj - 1;
   } else {
     if (P.g.cyc) return;
-    if (t < 2 || t > ny - 1) return;
+    if (t < P.g.jlo || t > P.g.jhi) return;
+    if (t + P.g.joff < 2 || t + P.g.joff > P.g.nyg - 1) return;
     gj = t; jj = t;
     gi = (side == 2) ? 1 : nx;
     ii = (side == 2) ? 2 : nx - 1;
@@ -260,6 +297,44 @@ __global__ __launch_bounds__(256) void k_lf_average(double *qo, const double *qo
         sc->ocncs[k] = 0.5 * (sc->ocncs[k] + sc->ocncsp[k]);
         sc->ocncn[k] = 0.5 * (sc->ocncn[k] + sc->ocncnp[k]);
       }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// y-slab halo messages: 3 rows of po and 1 row of qo per layer and direction.
+// message = [k][3 rows][ldx] of p, then [k][ldx] of q.   grid: (ceil(ldx/256), 4*nl, 2)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_pack(QgGeom g, const double *po, const double *qo, double *to_lower,
+                                                   double *to_upper) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.ldx) return;
+  const int rr = blockIdx.y % 4, k = blockIdx.y / 4; // rr 0..2: p rows, 3: q row
+  const int dir = blockIdx.z;                        // 0: to lower neighbour, 1: to upper
+  double *msg = dir == 0 ? to_lower : to_upper;
+  if (!msg) return;
+  if (rr < 3) {
+    const int j = dir == 0 ? g.jlo + rr : g.jhi - 2 + rr;
+    msg[((long)k * 3 + rr) * g.ldx + i] = po[g.fstride * k + (long)(j - 1) * g.ldx + i];
+  } else {
+    const int j = dir == 0 ? g.jlo : g.jhi;
+    msg[((long)g.nl * 3 + k) * g.ldx + i] = qo[g.fstride * k + (long)(j - 1) * g.ldx + i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_halo_unpack(QgGeom g, double *po, double *qo, const double *from_lower,
+                                                     const double *from_upper) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.ldx) return;
+  const int rr = blockIdx.y % 4, k = blockIdx.y / 4;
+  const int dir = blockIdx.z; // 0: message from the lower neighbour (its top rows), 1: from the upper
+  const double *msg = dir == 0 ? from_lower : from_upper;
+  if (!msg) return;
+  if (rr < 3) {
+    const int j = dir == 0 ? g.jlo - 3 + rr : g.jhi + 1 + rr;
+    po[g.fstride * k + (long)(j - 1) * g.ldx + i] = msg[((long)k * 3 + rr) * g.ldx + i];
+  } else {
+    const int j = dir == 0 ? g.jlo - 1 : g.jhi + 1;
+    qo[g.fstride * k + (long)(j - 1) * g.ldx + i] = msg[((long)g.nl * 3 + k) * g.ldx + i];
   }
 }
 

@@ -54,16 +54,17 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   __shared__ double sqo[H1 * W1];
 
   const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt, ldx = P.g.ldx;
+  const int nyg = P.g.nyg, joff = P.g.joff, jlo = P.g.jlo, jhi = P.g.jhi; // slab view (global row = local + joff)
   const long fs = P.g.fstride;
   const int tid = threadIdx.x;
   // ---- XCD-aware tile numbering ------------------------------------------
-  const int gx = (nx + TX - 1) / TX, gy = (ny + TY - 1) / TY;
+  const int gx = (nx + TX - 1) / TX, gy = (jhi - jlo + 1 + TY - 1) / TY;
   const int ntiles = gx * gy;
   const int per_xcd = (ntiles + 7) / 8;
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= ntiles || (int)(blockIdx.x >> 3) >= per_xcd) return;
   const int i0 = (tile % gx) * TX + 1; // first global i of the tile (1-based)
-  const int j0 = (tile / gx) * TY + 1;
+  const int j0 = (tile / gx) * TY + jlo; // first local row of the tile
   const int tx = tid % TX;
   const int ty0 = tid / TX; // 0..3
   constexpr int RPT = TY / (TEND_NT / TX); // rows per thread
@@ -101,9 +102,9 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   for (int r = 0; r < RPT; ++r) {
     int ly = ty0 + r * (TEND_NT / TX);
     int gi = i0 + tx, gj = j0 + ly;
-    bool in = gi <= nx && gj <= ny;
+    bool in = gi <= nx && gj <= jhi;
     long o = in ? (long)(gj - 1) * ldx + (gi - 1) : 0;
-    bool row = in && (gj == 1 || gj == ny);
+    bool row = in && (gj + joff == 1 || gj + joff == nyg);
     e_wek[r] = in ? P.wekpo[o] : 0.0;
     e_ent[r] = in ? P.entoc[o] : 0.0;
     e_ddy[r] = in ? P.ddynoc[o] : 0.0;
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
       double v = 0.0;
       bool inx = CYC ? (gi >= -1 && gi <= nx + 2) : (gi >= 1 && gi <= nx);
       if (gj >= 1 && gj <= ny && inx) {
-        if (gj == 1) v = bcf * (c[W3] - c[0]);
-        else if (gj == ny) v = bcf * (c[-W3] - c[0]);
+        if (gj + joff == 1) v = bcf * (c[W3] - c[0]);
+        else if (gj + joff == nyg) v = bcf * (c[-W3] - c[0]);
         else if (!CYC && gi == 1) v = bcf * (c[1] - c[0]);
         else if (!CYC && gi == nx) v = bcf * (c[-1] - c[0]);
         else v = (c[-W3] + c[-1] + c[1] + c[W3] - 4.0 * c[0]) * dxom2;
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
       double v = 0.0;
       bool inx = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
       if (gj >= 1 && gj <= ny && inx) {
-        if (gj == 1) v = bcf * (c[W2] - c[0]);
-        else if (gj == ny) v = bcf * (c[-W2] - c[0]);
+        if (gj + joff == 1) v = bcf * (c[W2] - c[0]);
+        else if (gj + joff == nyg) v = bcf * (c[-W2] - c[0]);
         else if (!CYC && gi == 1) v = bcf * (c[1] - c[0]);
         else if (!CYC && gi == nx) v = bcf * (c[-1] - c[0]);
         else v = dxom2 * (c[-W2] + c[-1] + c[1] + c[W2] - 4.0 * c[0]);
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
       int ly = ty0 + r * (TEND_NT / TX);
       int gi = i0 + tx, gj = j0 + ly;
       double val = 0.0;
-      bool interior = (gj >= 2 && gj <= ny - 1) && (CYC ? (gi >= 1 && gi <= nx) : (gi >= 2 && gi <= nx - 1));
+      bool interior = (gj <= jhi && gj + joff >= 2 && gj + joff <= nyg - 1) && (CYC ? (gi >= 1 && gi <= nx) : (gi >= 2 && gi <= nx - 1));
       if (interior) {
         const double *d4 = &sd4[(ly + 1) * W1 + (tx + 1)];
         const double *p = &spo[(ly + 1) * W1 + (tx + 1)];
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   for (int r = 0; r < RPT; ++r) {
     int ly = ty0 + r * (TEND_NT / TX);
     int gi = i0 + tx, gj = j0 + ly;
-    if (gi > nx || gj > ny) continue;
+    if (gi > nx || gj > jhi) continue;
     long o = (long)(gj - 1) * ldx + (gi - 1);
-    if (gj == 1 || gj == ny) {
+    if (gj + joff == 1 || gj + joff == nyg) {
       // rows not stepped: the new-qo buffer keeps qo (qgosubs.F:214-219)
 #pragma unroll
       for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = e_qo[k][r];

@@ -16,10 +16,17 @@
 // wavenumbers (one 128-B line) x 4 chunks per wave, a workgroup of 1024
 // threads covers a whole column block.  Each thread keeps its R rows in
 // registers, computes the chunk's affine map (C, D) with zero inflow, the
-// maps are composed through LDS, and the sweep is re-run from the true
-// inflow - so each row is read once and written once.
+// maps are composed by a wave scan, and the sweep is re-run from the true
+// inflow - so each row is read once and written once (PHASE 0).
 //
-// Algorithmic traffic: read w + write u (16 B per point).
+// y-slab decomposition (PHASE 1..3): the same idea one level up.  Each rank
+// reduces its slab to one affine map per wavenumber (phase 1), the maps are
+// all-gathered (nk*nl pairs of doubles instead of a transpose of the whole
+// array), the forward sweep is finished from the composed inflow and the
+// slab's backward map is produced (phase 2), a second all-gather, and the
+// backward sweep is finished (phase 3).
+//
+// Algorithmic traffic: read w + write u (16 B per point) for PHASE 0.
 #pragma once
 #include "qgcm_dev.h"
 
@@ -28,8 +35,22 @@
 #define TH_NT (TH_KW * TH_NC)
 static_assert(TH_NC == 64 && TH_KW == 16, "the chunk scan maps 64 chunks to the lanes of 16 waves");
 
+// Inclusive scan of affine maps over the 64 lanes of a wave (lane = position in
+// sweep order).  On return (Cs, Ds) is the composition of positions 0..lane.
+__device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double Cp = __shfl_up(Cs, off), Dp = __shfl_up(Ds, off);
+    if (lane >= off) {
+      Cs = Cs + Ds * Cp;
+      Ds = Ds * Dp;
+    }
+  }
+}
+
+// message layout of one rank: pairs (C, D) at 2*(m*ldw + k)
 // grid: (ceil(nk/16), nlayers)
-template <int R>
+template <int R, int PHASE>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __shared__ double sC[TH_NC][TH_KW];
   __shared__ double sD[TH_NC][TH_KW];
@@ -37,14 +58,18 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const int tid = threadIdx.x;
   const int kk = tid % TH_KW;
   const int c = tid / TH_KW;
+  const int lane = tid & 63, wv = tid >> 6;
   const int k = blockIdx.x * TH_KW + kk;
+  const int kq = blockIdx.x * TH_KW + wv; // wavenumber whose chunk maps this wave scans
   const int m = blockIdx.y;
-  const int nr = P.g.ny - 2; // rows j=2..ny-1  <->  r = 0..nr-1
+  const int nr = P.g.jr1 - P.g.jr0 + 1; // local rows jr0..jr1  <->  r = 0..nr-1
   const int ldw = P.g.ldw;
   const bool kok = k < P.g.nk;
   const double a = P.aoc;
-  double *wcol = P.wrk + P.g.wstride * m + (long)ldw + k;      // row j=2
+  double *wcol = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + k;
   const int r0 = c * R;
+  const bool first_rows = (P.g.jr0 + P.g.joff == 2); // slab starts at the first interior row
+  const long msg = 2L * P.g.nl * ldw;
 
   double w[R], b[R];
 #pragma unroll
@@ -60,7 +85,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       int r = r0 + t;
-      if (r == 0) {
+      if (r == 0 && first_rows) {
         betinv = 1.0 / boc;
       } else {
         double gam = a * betinv;
@@ -69,70 +94,109 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
       b[t] = (kok && r < nr) ? betinv : 0.0;
     }
   }
-  // ---- forward: local affine map (zero inflow) ---------------------------
-  double C = 0.0, D = 1.0;
+  double C, D;
+  if (PHASE != 3) {
+    // ---- forward: local affine map (zero inflow); rows past the slab are the identity
+    C = 0.0;
+    D = 1.0;
 #pragma unroll
-  for (int t = 0; t < R; ++t) {
-    C = (w[t] - a * C) * b[t];
-    D = -a * b[t] * D;
+    for (int t = 0; t < R; ++t) {
+      if (r0 + t < nr) {
+        C = (w[t] - a * C) * b[t];
+        D = -a * b[t] * D;
+      }
+    }
+    sC[c][kk] = C;
+    sD[c][kk] = D;
+    __syncthreads();
+    double Cs = sC[lane][wv], Ds = sD[lane][wv];
+    affine_scan(Cs, Ds, lane);
+    if (PHASE == 1) {
+      // slab map = composition of all chunks: publish and stop
+      if (lane == 63 && kq < P.g.nk) {
+        P.send[2 * ((long)m * ldw + kq)] = Cs;
+        P.send[2 * ((long)m * ldw + kq) + 1] = Ds;
+      }
+      return;
+    }
+    // value entering the slab: compose the maps of the ranks before this one
+    double uin = 0.0;
+    if (PHASE == 2 && kq < P.g.nk) {
+      for (int rk = 0; rk < P.rank; ++rk) {
+        double Cr = P.gath[rk * msg + 2 * ((long)m * ldw + kq)];
+        double Dr = P.gath[rk * msg + 2 * ((long)m * ldw + kq) + 1];
+        uin = Cr + Dr * uin;
+      }
+    }
+    // value entering chunk `lane` = scanned map of chunk lane-1 applied to uin
+    {
+      double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
+      sIn[lane][wv] = (lane == 0) ? uin : Cprev + Dprev * uin;
+    }
+    __syncthreads();
+    double u = sIn[c][kk];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      if (r0 + t < nr) {
+        u = (w[t] - a * u) * b[t];
+        w[t] = u;
+      }
+    }
+    if (PHASE == 2) {
+      // the forward result is needed again after the second exchange
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        int r = r0 + t;
+        if (kok && r < nr) wcol[(long)r * ldw] = w[t];
+      }
+    }
+    __syncthreads(); // sC/sD/sIn are reused by the backward sweep
+  }
+  // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
+  C = 0.0;
+  D = 1.0;
+#pragma unroll
+  for (int t = R - 1; t >= 0; --t) {
+    if (r0 + t < nr) {
+      C = w[t] - a * b[t] * C;
+      D = -a * b[t] * D;
+    }
   }
   sC[c][kk] = C;
   sD[c][kk] = D;
   __syncthreads();
-  // Compose the 64 chunk maps of one wavenumber with a wave scan: wave w takes
-  // wavenumber kk = w, lane = chunk.  After the inclusive scan Cs is the value
-  // leaving each chunk (the inflow to chunk 0 is zero), so the inflow of chunk c
-  // is the scanned value of chunk c-1.
-  const int lane = tid & 63, wv = tid >> 6;
-  {
-    double Cs = sC[lane][wv], Ds = sD[lane][wv];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      double Cp = __shfl_up(Cs, off), Dp = __shfl_up(Ds, off);
-      if (lane >= off) {
-        Cs = Cs + Ds * Cp;
-        Ds = Ds * Dp;
-      }
+  // sweep order is last chunk first: lane l stands for chunk 63-l
+  const int cr = 63 - lane;
+  double Cs = sC[cr][wv], Ds = sD[cr][wv];
+  affine_scan(Cs, Ds, lane);
+  if (PHASE == 2) {
+    if (lane == 63 && kq < P.g.nk) {
+      P.send[2 * ((long)m * ldw + kq)] = Cs;
+      P.send[2 * ((long)m * ldw + kq) + 1] = Ds;
     }
-    double inflow = __shfl_up(Cs, 1);
-    sIn[lane][wv] = (lane == 0) ? 0.0 : inflow;
+    return;
   }
-  __syncthreads();
-  double u = sIn[c][kk];
-#pragma unroll
-  for (int t = 0; t < R; ++t) {
-    u = (w[t] - a * u) * b[t];
-    w[t] = u;
-  }
-  // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
-  C = 0.0;
-#pragma unroll
-  for (int t = R - 1; t >= 0; --t) C = w[t] - a * b[t] * C;
-  __syncthreads();
-  sC[c][kk] = C; // D is the same product as in the forward sweep
-  __syncthreads();
-  {
-    // same scan in the opposite direction: lane l stands for chunk 63-l
-    const int cr = 63 - lane;
-    double Cs = sC[cr][wv], Ds = sD[cr][wv];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      double Cp = __shfl_up(Cs, off), Dp = __shfl_up(Ds, off);
-      if (lane >= off) {
-        Cs = Cs + Ds * Cp;
-        Ds = Ds * Dp;
-      }
+  double vin = 0.0;
+  if (PHASE == 3 && kq < P.g.nk) {
+    for (int rk = P.nranks - 1; rk > P.rank; --rk) {
+      double Cr = P.gath[rk * msg + 2 * ((long)m * ldw + kq)];
+      double Dr = P.gath[rk * msg + 2 * ((long)m * ldw + kq) + 1];
+      vin = Cr + Dr * vin;
     }
-    double inflow = __shfl_up(Cs, 1);
-    sIn[cr][wv] = (lane == 0) ? 0.0 : inflow;
+  }
+  {
+    double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
+    sIn[cr][wv] = (lane == 0) ? vin : Cprev + Dprev * vin;
   }
   __syncthreads();
   double v = sIn[c][kk];
   const double ft = P.ftnorm;
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
-    v = w[t] - a * b[t] * v;
-    w[t] = v;
+    if (r0 + t < nr) {
+      v = w[t] - a * b[t] * v;
+      w[t] = v;
+    }
   }
 #pragma unroll
   for (int t = 0; t < R; ++t) {

@@ -41,12 +41,15 @@ struct QgConstr {
 
 // geometry shared by all kernels
 struct QgGeom {
-  int nx, ny, nl, cyc;
+  int nx, ny, nl, cyc; // ny = rows of the LOCAL arrays (owned rows + halo rows)
   int nxt;        // nxto = nx-1
   int nk;         // spectral coefficients per row
   int ldx, ldw;   // row pitches (doubles)
   long fstride;   // ldx*ny
   long wstride;   // ldw*ny
+  // y-slab view: global row = local row + joff; this handle owns local rows jlo..jhi;
+  // jr0..jr1 = owned rows that are interior to the global domain (2..nyg-1).
+  int nyg, joff, jlo, jhi, jr0, jr1;
 };
 
 struct QgTendParams {
@@ -76,6 +79,9 @@ struct QgDstParams {
 
 struct QgThomasParams {
   QgGeom g;
+  const double *gath; // distributed sweep: all ranks' slab maps (rank-major), else nullptr
+  double *send;       // distributed sweep: this rank's slab map
+  int rank, nranks;
   double *wrk;
   const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index
   const double *betc; // (ldw, TH_NC, nlayers): pivot entering each chunk of rows
@@ -105,6 +111,8 @@ struct QgBdyParams {
 
 struct QgConstrParams {
   QgGeom g;
+  const double *partials; // y-slab run: all ranks' xin partials (rank-major), npart ranks
+  int npart;
   const double *rowsum;
   const double *wrk;
   QgScalars *sc;

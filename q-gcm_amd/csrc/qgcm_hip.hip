@@ -54,6 +54,7 @@ struct qgcm_hip_ctx {
   int fftN, nfac, fac[QG_MAXFAC];
   QgConstr cs;
   bool grid_set, homog_set;
+  bool whole; // the handle owns the whole domain (no y-slab neighbours)
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
@@ -127,7 +128,22 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   c->prm = *prm;
   HIPCHECK(hipGetDevice(&c->device));
   QgGeom &g = c->g;
-  g.nx = prm->nxpo; g.ny = prm->nypo; g.nl = prm->nlo; g.cyc = prm->cyclic;
+  g.nx = prm->nxpo; g.nl = prm->nlo; g.cyc = prm->cyclic;
+  g.nyg = prm->nypo;
+  {
+    // y-slab view: owned global rows g0..g1 (+ 3 halo rows towards each neighbour)
+    int g0 = prm->slab_g0, g1 = prm->slab_g1;
+    if (g0 == 0 && g1 == 0) { g0 = 1; g1 = g.nyg; }
+    if (g0 < 1 || g1 > g.nyg || g1 - g0 + 1 < 4) QG_FAIL("qgcm_hip_create: bad slab %d..%d of %d rows (need >= 4 rows)", g0, g1, g.nyg);
+    const int hlo = g0 > 1 ? 3 : 0, hhi = g1 < g.nyg ? 3 : 0;
+    g.ny = (g1 - g0 + 1) + hlo + hhi;
+    g.joff = g0 - hlo - 1;
+    g.jlo = hlo + 1;
+    g.jhi = hlo + (g1 - g0 + 1);
+    g.jr0 = (g0 == 1) ? g.jlo + 1 : g.jlo;       // rows 2..nyg-1 of the global grid that this slab owns
+    g.jr1 = (g1 == g.nyg) ? g.jhi - 1 : g.jhi;
+    c->whole = (g0 == 1 && g1 == g.nyg);
+  }
   g.nxt = g.nx - 1;
   g.nk = g.cyc ? g.nxt : g.nxt - 1;
   g.ldx = round_up(g.nx, 16);
@@ -185,8 +201,8 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   return 0;
 }
 
-static int thomas_rows_per_chunk(int ny) {
-  const int need = (ny - 2 + TH_NC - 1) / TH_NC;
+static int thomas_rows_per_chunk(int nrows) {
+  const int need = (nrows + TH_NC - 1) / TH_NC;
   for (int r : {1, 2, 4, 8, 16, 32})
     if (need <= r) return r;
   return -1;
@@ -196,17 +212,19 @@ static int thomas_rows_per_chunk(int ny) {
 // entering each chunk of R rows is kept (the kernel re-runs the recurrence).
 static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* per spectral index */,
                        double *boc_out /* ldw */, double *betc /* TH_NC*ldw */) {
-  const int nr = g.ny - 2;
+  const int nr = g.jr1 - g.jr0 + 1;         // rows of this slab
+  const int rg0 = g.jr0 + g.joff - 2;       // global interior-row index of the slab's first row
   for (int k = 0; k < g.nk; ++k) {
     boc_out[k] = boc[k];
-    double betinv = 1.0 / boc[k]; // row r = 0
-    for (int r = 0; r < nr; ++r) {
-      if (r > 0) {
+    double betinv = 1.0 / boc[k]; // global interior row 0
+    for (int rg = 0; rg < rg0 + nr; ++rg) {
+      if (rg > 0) {
         double gam = aoc * betinv;
         betinv = 1.0 / (boc[k] - aoc * gam);
       }
-      // betinv is now the pivot of row r; it enters the chunk that starts at r+1
-      if ((r + 1) % R == 0 && (r + 1) / R < TH_NC) betc[(size_t)((r + 1) / R) * g.ldw + k] = betinv;
+      // betinv is the pivot of global row rg; it enters the chunk that starts at local row rg+1-rg0
+      const int rl = rg + 1 - rg0;
+      if (rl >= 0 && rl % R == 0 && rl / R < TH_NC) betc[(size_t)(rl / R) * g.ldw + k] = betinv;
     }
   }
 }
@@ -220,8 +238,8 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   }
   c->bd2oc.assign(bd2oc, bd2oc + g.nxt);
   // Thomas diagonal + chunk-entry pivots per mode: boc = bd2oc - rdm2oc(m)   (src/ocisubs.F:148-150)
-  c->thR = thomas_rows_per_chunk(g.ny);
-  if (c->thR < 0) QG_FAIL("qgcm_hip_set_grid: nypo=%d exceeds the single-segment Thomas kernel (<= 2050)", g.ny);
+  c->thR = thomas_rows_per_chunk(g.jr1 - g.jr0 + 1);
+  if (c->thR < 0) QG_FAIL("qgcm_hip_set_grid: %d rows per slab exceed the single-segment Thomas kernel (<= 2048)", g.jr1 - g.jr0 + 1);
   {
     std::vector<double> bocv((size_t)g.ldw * g.nl, 0.0), betc((size_t)g.ldw * TH_NC * g.nl, 0.0), boc(g.nk);
     for (int m = 0; m < g.nl; ++m) {
@@ -471,7 +489,7 @@ static int launch_tend(qgcm_hip_ctx *c) {
     P.ah4fac[k] = pr.ah4oc[k] / pr.fnot;
   }
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
-  const int ntiles = ((g.nx + TEND_TX - 1) / TEND_TX) * ((g.ny + TEND_TY - 1) / TEND_TY);
+  const int ntiles = ((g.nx + TEND_TX - 1) / TEND_TX) * ((g.jhi - g.jlo + 1 + TEND_TY - 1) / TEND_TY);
   dim3 grid(8 * ((ntiles + 7) / 8)); // 1-D: the kernel maps blockIdx -> tile per XCD band
   KTimer t(c, KN_TEND);
   switch (g.nl) {
@@ -497,7 +515,7 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse) {
   P.nfac = c->nfac;
   for (int f = 0; f < c->nfac; ++f) P.fac[f] = c->fac[f];
   P.nlayers = nlayers;
-  const int nrows = g.ny - 2;
+  const int nrows = g.jr1 - g.jr0 + 1;
   const int npairs = (nrows + 1) / 2;
   dim3 grid(npairs, nlayers);
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
@@ -515,11 +533,13 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse) {
   return 0;
 }
 
-static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers) {
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers,
+                         int phase = 0, const double *gath = nullptr, double *send = nullptr, int rank = 0, int nranks = 1) {
   const QgGeom &g = c->g;
   QgThomasParams P;
   memset(&P, 0, sizeof(P));
   P.g = g;
+  P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
   P.wrk = wrk;
   P.boc = boc;
   P.betc = betc;
@@ -528,23 +548,49 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
   P.nlayers = nlayers;
   dim3 grid((g.nk + TH_KW - 1) / TH_KW, nlayers);
   KTimer t(c, KN_THOMAS);
+#define QG_TH(RV)                                                                                    \
+  switch (phase) {                                                                                   \
+    case 0: hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, c->stream, P); break;        \
+    case 1: hipLaunchKernelGGL((k_thomas<RV, 1>), grid, dim3(TH_NT), 0, c->stream, P); break;        \
+    case 2: hipLaunchKernelGGL((k_thomas<RV, 2>), grid, dim3(TH_NT), 0, c->stream, P); break;        \
+    default: hipLaunchKernelGGL((k_thomas<RV, 3>), grid, dim3(TH_NT), 0, c->stream, P); break;       \
+  }
   switch (c->thR) {
-    case 1: hipLaunchKernelGGL((k_thomas<1>), grid, dim3(TH_NT), 0, c->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_thomas<2>), grid, dim3(TH_NT), 0, c->stream, P); break;
-    case 4: hipLaunchKernelGGL((k_thomas<4>), grid, dim3(TH_NT), 0, c->stream, P); break;
-    case 8: hipLaunchKernelGGL((k_thomas<8>), grid, dim3(TH_NT), 0, c->stream, P); break;
-    case 16: hipLaunchKernelGGL((k_thomas<16>), grid, dim3(TH_NT), 0, c->stream, P); break;
-    case 32: hipLaunchKernelGGL((k_thomas<32>), grid, dim3(TH_NT), 0, c->stream, P); break;
-    default: QG_FAIL("k_thomas: nypo too large for the single-segment kernel");
+    case 1: QG_TH(1); break;
+    case 2: QG_TH(2); break;
+    case 4: QG_TH(4); break;
+    case 8: QG_TH(8); break;
+    case 16: QG_TH(16); break;
+    case 32: QG_TH(32); break;
+    default: QG_FAIL("k_thomas: too many rows for the single-segment kernel");
+  }
+#undef QG_TH
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P);
+
+static int launch_constr(qgcm_hip_ctx *c, const double *partials = nullptr, int npart = 0) {
+  const QgGeom &g = c->g;
+  QgConstrParams P;
+  fill_constr_params(c, P);
+  P.partials = partials;
+  P.npart = npart;
+  KTimer t(c, KN_CONSTR);
+  switch (g.nl) {
+    case 2: hipLaunchKernelGGL((k_constr_box<2>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 3: hipLaunchKernelGGL((k_constr_box<3>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL((k_constr_box<4>), dim3(1), dim3(64), 0, c->stream, P); break;
+    default: QG_FAIL("k_constr: unsupported nlo");
   }
   HIPCHECK(hipGetLastError());
   return 0;
 }
 
-static int launch_constr(qgcm_hip_ctx *c) {
+static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
-  QgConstrParams P;
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.rowsum = c->rowsum;
@@ -560,15 +606,6 @@ static int launch_constr(qgcm_hip_ctx *c) {
     P.ctl2m[i] = pr.ctl2moc[i];
     P.ctm2l[i] = pr.ctm2loc[i];
   }
-  KTimer t(c, KN_CONSTR);
-  switch (g.nl) {
-    case 2: hipLaunchKernelGGL((k_constr_box<2>), dim3(1), dim3(64), 0, c->stream, P); break;
-    case 3: hipLaunchKernelGGL((k_constr_box<3>), dim3(1), dim3(64), 0, c->stream, P); break;
-    case 4: hipLaunchKernelGGL((k_constr_box<4>), dim3(1), dim3(64), 0, c->stream, P); break;
-    default: QG_FAIL("k_constr: unsupported nlo");
-  }
-  HIPCHECK(hipGetLastError());
-  return 0;
 }
 
 static void fill_bdy_params(qgcm_hip_ctx *c, QgBdyParams &P);
@@ -586,7 +623,7 @@ static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
   QgBdyParams B;
   fill_bdy_params(c, B); // B.qo = current qo; B.po unused by the fused kernel
-  dim3 grid((g.nx + 255) / 256, g.ny);
+  dim3 grid((g.nx + 255) / 256, g.jhi - g.jlo + 1);
   KTimer t(c, KN_UNPACK);
 #define QG_UNPACK(NLV)                                                                                   \
   if (fuse_bdy) hipLaunchKernelGGL((k_unpack_box<NLV, true>), grid, dim3(256), 0, c->stream, P, B);      \
@@ -655,6 +692,7 @@ extern "C" int qgcm_hip_qgostep(qgcm_hip_handle c) {
 
 static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
   if (check_ready(c, "qgcm_hip_ocinvq")) return 1;
+  if (!c->whole) QG_FAIL("qgcm_hip_ocinvq: this handle is a y-slab; drive it with the slab building blocks");
   if (!c->homog_set) QG_FAIL("qgcm_hip_ocinvq: homogeneous solutions not set");
   if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
   if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl)) return 1;
@@ -714,6 +752,7 @@ static int get_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
 
 extern "C" int qgcm_hip_steps(qgcm_hip_handle c, int s0, int n) {
   if (check_ready(c, "qgcm_hip_steps")) return 1;
+  if (!c->whole) QG_FAIL("qgcm_hip_steps: this handle is a y-slab; drive it with the slab building blocks");
   if (s0 < 1 || n < 0) QG_FAIL("qgcm_hip_steps: bad step range");
   int s = s0;
   while (n >= kGraphBlock && !c->profiling) {
@@ -737,6 +776,7 @@ extern "C" int qgcm_hip_sync(qgcm_hip_handle c) {
 extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *boc) {
   if (check_ready(c, "qgcm_hip_helmholtz")) return 1;
   if (!wrk || !boc) QG_FAIL("qgcm_hip_helmholtz: null argument");
+  if (!c->whole) QG_FAIL("qgcm_hip_helmholtz: only for a handle that owns the whole domain");
   const QgGeom &g = c->g;
   // pivots for this boc (box: boc(i-1) multiplies sine wavenumber i-1, src/ocisubs.F:470-478)
   std::vector<double> bocv((size_t)g.ldw, 0.0), betc((size_t)g.ldw * TH_NC, 0.0);
@@ -762,6 +802,83 @@ extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *
     wrk[i] = 0.0;
     wrk[(size_t)(g.ny - 1) * g.nx + i] = 0.0;
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// y-slab building blocks
+// ---------------------------------------------------------------------------
+extern "C" int qgcm_hip_local_rows(qgcm_hip_handle c, int *nyl, int *joff, int *jlo, int *jhi) {
+  if (!c) QG_FAIL("qgcm_hip_local_rows: null handle");
+  if (nyl) *nyl = c->g.ny;
+  if (joff) *joff = c->g.joff;
+  if (jlo) *jlo = c->g.jlo;
+  if (jhi) *jhi = c->g.jhi;
+  return 0;
+}
+
+extern "C" int qgcm_hip_row_transform(qgcm_hip_handle c, int inverse) {
+  if (check_ready(c, "qgcm_hip_row_transform")) return 1;
+  return launch_dst(c, c->wrk, c->g.nl, inverse != 0);
+}
+
+extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? 2 * c->g.nl * c->g.ldw : 0; }
+
+extern "C" int qgcm_hip_thomas_phase(qgcm_hip_handle c, int phase, const double *gath_dev, double *send_dev, int rank,
+                                     int nranks) {
+  if (check_ready(c, "qgcm_hip_thomas_phase")) return 1;
+  if (phase < 1 || phase > 3) QG_FAIL("qgcm_hip_thomas_phase: phase must be 1, 2 or 3");
+  if ((phase != 3 && !send_dev) || (phase != 1 && !gath_dev)) QG_FAIL("qgcm_hip_thomas_phase: missing buffer");
+  return launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, phase, gath_dev, send_dev, rank, nranks);
+}
+
+extern "C" int qgcm_hip_xin_partial(qgcm_hip_handle c, double *send_dev) {
+  if (check_ready(c, "qgcm_hip_xin_partial")) return 1;
+  QgConstrParams P;
+  fill_constr_params(c, P);
+  switch (c->g.nl) {
+    case 2: hipLaunchKernelGGL((k_xin_partial<2>), dim3(1), dim3(64), 0, c->stream, P, send_dev); break;
+    case 3: hipLaunchKernelGGL((k_xin_partial<3>), dim3(1), dim3(64), 0, c->stream, P, send_dev); break;
+    case 4: hipLaunchKernelGGL((k_xin_partial<4>), dim3(1), dim3(64), 0, c->stream, P, send_dev); break;
+    default: QG_FAIL("k_xin_partial: unsupported nlo");
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int qgcm_hip_constr_partials(qgcm_hip_handle c, const double *gath_dev, int nranks) {
+  if (check_ready(c, "qgcm_hip_constr_partials")) return 1;
+  if (!c->homog_set) QG_FAIL("qgcm_hip_constr_partials: homogeneous solutions not set");
+  return launch_constr(c, gath_dev, nranks);
+}
+
+extern "C" int qgcm_hip_unpack(qgcm_hip_handle c, int fuse_ocqbdy) {
+  if (check_ready(c, "qgcm_hip_unpack")) return 1;
+  if (launch_unpack(c, fuse_ocqbdy != 0)) return 1;
+  c->ip ^= 1;
+  return 0;
+}
+
+extern "C" int qgcm_hip_halo_msg_len(qgcm_hip_handle c) { return c ? 4 * c->g.nl * c->g.ldx : 0; }
+
+extern "C" int qgcm_hip_halo_pack(qgcm_hip_handle c, double *to_lower_dev, double *to_upper_dev) {
+  if (check_ready(c, "qgcm_hip_halo_pack")) return 1;
+  const QgGeom &g = c->g;
+  dim3 grid((g.ldx + 255) / 256, 4 * g.nl, 2);
+  hipLaunchKernelGGL(k_halo_pack, grid, dim3(256), 0, c->stream, g, (const double *)c->p[c->ip],
+                     (const double *)c->q[c->iq], to_lower_dev, to_upper_dev);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int qgcm_hip_halo_unpack(qgcm_hip_handle c, const double *from_lower_dev, const double *from_upper_dev) {
+  if (check_ready(c, "qgcm_hip_halo_unpack")) return 1;
+  const QgGeom &g = c->g;
+  if ((from_lower_dev && g.jlo < 4) || (from_upper_dev && g.ny - g.jhi < 3)) QG_FAIL("qgcm_hip_halo_unpack: no halo rows on that side");
+  dim3 grid((g.ldx + 255) / 256, 4 * g.nl, 2);
+  hipLaunchKernelGGL(k_halo_unpack, grid, dim3(256), 0, c->stream, g, c->p[c->ip], c->q[c->iq], from_lower_dev,
+                     from_upper_dev);
+  HIPCHECK(hipGetLastError());
   return 0;
 }
 

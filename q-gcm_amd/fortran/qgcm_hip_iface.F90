@@ -21,6 +21,7 @@ module qgcm_hip_iface
     real(c_double) :: ctm2loc(QGCM_HIP_MAXL*QGCM_HIP_MAXL)
     real(c_double) :: rdm2oc(QGCM_HIP_MAXL)
     real(c_double) :: aoc
+    integer(c_int) :: slab_g0, slab_g1
   end type qgcm_hip_params
 
   interface

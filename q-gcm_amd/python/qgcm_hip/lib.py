@@ -25,6 +25,7 @@ class Params(C.Structure):
         ("amatoc", C.c_double * (MAXL * MAXL)), ("ctl2moc", C.c_double * (MAXL * MAXL)),
         ("ctm2loc", C.c_double * (MAXL * MAXL)), ("rdm2oc", C.c_double * MAXL),
         ("aoc", C.c_double),
+        ("slab_g0", C.c_int), ("slab_g1", C.c_int),
     ]
 
 
@@ -36,6 +37,9 @@ SYMBOLS = [
     "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag",
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
+    "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
+    "qgcm_hip_xin_partial", "qgcm_hip_constr_partials", "qgcm_hip_unpack",
+    "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack",
     "qgcm_hip_time_steps", "qgcm_hip_profile_steps", "qgcm_hip_copy_bandwidth", "qgcm_hip_stream",
 ]
 
@@ -71,6 +75,17 @@ def load_library():
         getattr(L, n).argtypes = [vp]
     L.qgcm_hip_steps.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_helmholtz.argtypes = [vp, dp, dp]
+    ip = C.POINTER(C.c_int)
+    L.qgcm_hip_local_rows.argtypes = [vp, ip, ip, ip, ip]
+    L.qgcm_hip_row_transform.argtypes = [vp, C.c_int]
+    L.qgcm_hip_thomas_msg_len.argtypes = [vp]
+    L.qgcm_hip_thomas_phase.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int]
+    L.qgcm_hip_xin_partial.argtypes = [vp, vp]
+    L.qgcm_hip_constr_partials.argtypes = [vp, vp, C.c_int]
+    L.qgcm_hip_unpack.argtypes = [vp, C.c_int]
+    L.qgcm_hip_halo_msg_len.argtypes = [vp]
+    L.qgcm_hip_halo_pack.argtypes = [vp, vp, vp]
+    L.qgcm_hip_halo_unpack.argtypes = [vp, vp, vp]
     L.qgcm_hip_time_steps.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.qgcm_hip_profile_steps.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_int),
                                          C.POINTER(C.c_char_p), C.POINTER(C.c_int)]

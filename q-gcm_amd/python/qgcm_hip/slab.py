@@ -1,0 +1,321 @@
+"""y-slab decomposition of the ocean hot path across GPUs (one process per GPU).
+
+The reference is a single-process OpenMP code; this decomposition is new design
+(SURVEY 8e).  Rank r owns a contiguous range of rows j for all i and layers - x is
+never split, so the tendency kernel, the row transforms and the unpack stay local.
+Per ocean step the ranks exchange
+
+  * the slab summaries of the tridiagonal sweeps along y (two all-gathers of
+    2*nlo*nk doubles: the chunk-scan of k_thomas one level up, instead of an
+    all-to-all transpose of the whole work array),
+  * the nlo partial area integrals (all-gather, summed in rank order so every rank
+    gets bit-identical constraint coefficients),
+  * halo rows of the new po (3 rows: del-6 of the lagged field) and qo (1 row).
+
+`SlabOcean` is the orchestration; it is independent of where the slab kernels
+run (`HipSlab`: the C ABI on a GPU) and of the transport (`LocalComm`: several
+slabs in one process, used to test the decomposition on one GPU; `DistComm`:
+torch.distributed, "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests).
+All message buffers are torch tensors.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hostinit
+from .lib import Params, check, load_library
+
+HALO = 3
+
+
+def partition(nyg, nranks):
+    """Global row ranges (1-based, inclusive) of the y-slabs: near-equal, contiguous."""
+    base, rem = divmod(nyg, nranks)
+    out, g = [], 1
+    for r in range(nranks):
+        n = base + (1 if r < rem else 0)
+        out.append((g, g + n - 1))
+        g += n
+    return out
+
+
+def local_rows(nyg, g0, g1):
+    """(nyl, joff, jlo, jhi): local array rows, global = local + joff, owned local range."""
+    hlo = HALO if g0 > 1 else 0
+    hhi = HALO if g1 < nyg else 0
+    return (g1 - g0 + 1) + hlo + hhi, g0 - hlo - 1, hlo + 1, hlo + (g1 - g0 + 1)
+
+
+def slab_slice(nyg, g0, g1):
+    """numpy slice (0-based) of the global rows held locally (owned + halos)."""
+    nyl, joff, _, _ = local_rows(nyg, g0, g1)
+    return slice(joff, joff + nyl)
+
+
+# --------------------------------------------------------------------------
+# transports
+# --------------------------------------------------------------------------
+class LocalComm:
+    """All slabs live in this process (virtual ranks)."""
+
+    def __init__(self, nranks, after=None):
+        self.nranks = nranks
+        self.local_ranks = list(range(nranks))
+        self.after = after  # e.g. torch.cuda.synchronize when the buffers are device tensors
+
+    def all_gather(self, gath, send):
+        n = send[0].numel()
+        for g in gath:
+            for r, s in enumerate(send):
+                g[r * n:(r + 1) * n].copy_(s)
+        if self.after:
+            self.after()
+
+    def halo_exchange(self, to_lo, to_hi, from_lo, from_hi):
+        for r in range(self.nranks):
+            if r > 0:
+                from_lo[r].copy_(to_hi[r - 1])
+            if r < self.nranks - 1:
+                from_hi[r].copy_(to_lo[r + 1])
+        if self.after:
+            self.after()
+
+
+class DistComm:
+    """One slab per process over torch.distributed (backend nccl = RCCL, or gloo)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.nranks = dist.get_world_size(group)
+        self.local_ranks = [self.rank]
+
+    def all_gather(self, gath, send):
+        self.dist.all_gather_into_tensor(gath[0], send[0], group=self.group)
+
+    def halo_exchange(self, to_lo, to_hi, from_lo, from_hi):
+        d, r = self.dist, self.rank
+        ops = []
+        if r > 0:
+            ops += [d.P2POp(d.isend, to_lo[0], r - 1, self.group), d.P2POp(d.irecv, from_lo[0], r - 1, self.group)]
+        if r < self.nranks - 1:
+            ops += [d.P2POp(d.isend, to_hi[0], r + 1, self.group), d.P2POp(d.irecv, from_hi[0], r + 1, self.group)]
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+
+
+# --------------------------------------------------------------------------
+# one slab on one GPU through the C ABI
+# --------------------------------------------------------------------------
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HipSlab:
+    """The slab kernels of include/qgcm_hip.h ("y-slab building blocks")."""
+
+    def __init__(self, cfg, consts, g0, g1, rank, nranks, device=-1, sync_each_call=False):
+        import torch
+        self.torch = torch
+        self.cfg, self.rank, self.nranks = cfg, rank, nranks
+        self.g0, self.g1 = g0, g1
+        self.L = load_library()
+        nl, nyg = cfg.nlo, cfg.nypo
+        self.nyl, self.joff, self.jlo, self.jhi = local_rows(nyg, g0, g1)
+        sl = slab_slice(nyg, g0, g1)
+        p = Params()
+        p.nxpo, p.nypo, p.nlo, p.cyclic = cfg.nxpo, nyg, nl, int(cfg.cyclic)
+        p.fnot, p.beta, p.dxo, p.dyo = cfg.fnot, cfg.beta, cfg.dxo, cfg.dyo
+        p.tdto, p.delek, p.bccooc, p.aoc = cfg.tdto, cfg.delek, cfg.bccooc, consts["aoc"]
+        p.slab_g0, p.slab_g1 = g0, g1
+        for k in range(nl):
+            p.ah2oc[k], p.ah4oc[k], p.hoc[k], p.rdm2oc[k] = cfg.ah2oc[k], cfg.ah4oc[k], cfg.hoc[k], consts["rdm2oc"][k]
+        for k in range(nl - 1):
+            p.gpoc[k] = cfg.gpoc[k]
+        for name in ("amatoc", "ctl2moc", "ctm2loc"):
+            arr = getattr(p, name)
+            for i, v in enumerate(np.asarray(consts[name]).ravel(order="F")):
+                arr[i] = v
+        self.h = C.c_void_p()
+        check(self.L.qgcm_hip_create(C.byref(self.h), C.byref(p), int(device)))
+        yp = np.ascontiguousarray(consts["yporel"][sl])
+        bd2 = np.ascontiguousarray(consts["bd2oc"])
+        dd = np.asfortranarray(consts["ddynoc"][:, sl])
+        check(self.L.qgcm_hip_set_grid(self.h, _dp(yp), _dp(bd2), _dp(dd)))
+        oh = np.asfortranarray(consts["ochom"][:, sl, :])
+        cd, ch = np.asfortranarray(consts["cdiffo"]), np.asfortranarray(consts["cdhoc"])
+        check(self.L.qgcm_hip_set_homog_box(self.h, _dp(oh), _dp(cd), _dp(ch)))
+        self.sync_each_call = sync_each_call
+        self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+        self.th_len = self.L.qgcm_hip_thomas_msg_len(self.h)
+        self.halo_len = self.L.qgcm_hip_halo_msg_len(self.h)
+        self.stream_ptr = self.L.qgcm_hip_stream(self.h)
+
+    # buffers -------------------------------------------------------------
+    def new_buffer(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _done(self):
+        if self.sync_each_call:
+            check(self.L.qgcm_hip_sync(self.h))
+
+    def sync(self):
+        check(self.L.qgcm_hip_sync(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.qgcm_hip_destroy(self.h)
+            self.h = None
+
+    # state (local blocks incl. halos) ---------------------------------------
+    def set_state(self, po, pom, qo, qom):
+        a = [np.asfortranarray(x, dtype=np.float64) for x in (po, pom, qo, qom)]
+        check(self.L.qgcm_hip_set_state(self.h, *[_dp(x) for x in a]))
+
+    def get_state(self):
+        a = [np.zeros((self.cfg.nxpo, self.nyl, self.cfg.nlo), order="F") for _ in range(4)]
+        check(self.L.qgcm_hip_get_state(self.h, *[_dp(x) for x in a]))
+        return a
+
+    def set_forcing(self, wekpo, entoc, xon):
+        w, e = np.asfortranarray(wekpo, dtype=np.float64), np.asfortranarray(entoc, dtype=np.float64)
+        x = np.ascontiguousarray(xon, dtype=np.float64)
+        check(self.L.qgcm_hip_set_forcing(self.h, _dp(w), _dp(e), _dp(x)))
+
+    def set_scalars(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        check(self.L.qgcm_hip_set_scalars(self.h, _dp(s)))
+
+    def get_scalars(self):
+        s = np.zeros(2 * (self.cfg.nlo - 1) + 4 * self.cfg.nlo)
+        check(self.L.qgcm_hip_get_scalars(self.h, _dp(s)))
+        return s
+
+    # slab kernels -------------------------------------------------------------
+    def qgostep(self):
+        check(self.L.qgcm_hip_qgostep(self.h)); self._done()
+
+    def row_transform(self, inverse):
+        check(self.L.qgcm_hip_row_transform(self.h, int(inverse))); self._done()
+
+    def thomas_phase(self, phase, gath, send):
+        check(self.L.qgcm_hip_thomas_phase(self.h, int(phase), self._ptr(gath), self._ptr(send), self.rank, self.nranks))
+        self._done()
+
+    def xin_partial(self, send):
+        check(self.L.qgcm_hip_xin_partial(self.h, self._ptr(send))); self._done()
+
+    def constr_partials(self, gath):
+        check(self.L.qgcm_hip_constr_partials(self.h, self._ptr(gath), self.nranks)); self._done()
+
+    def unpack(self, fuse_ocqbdy=True):
+        check(self.L.qgcm_hip_unpack(self.h, int(fuse_ocqbdy))); self._done()
+
+    def halo_pack(self, to_lo, to_hi):
+        check(self.L.qgcm_hip_halo_pack(self.h, self._ptr(to_lo), self._ptr(to_hi))); self._done()
+
+    def halo_unpack(self, from_lo, from_hi):
+        check(self.L.qgcm_hip_halo_unpack(self.h, self._ptr(from_lo), self._ptr(from_hi))); self._done()
+
+    def lf_average(self):
+        check(self.L.qgcm_hip_lf_average(self.h)); self._done()
+
+
+# --------------------------------------------------------------------------
+# orchestration
+# --------------------------------------------------------------------------
+class SlabOcean:
+    """The distributed ocean step.  `slabs` are the slab objects this process owns
+    (one per local rank of `comm`); a slab object provides the methods of HipSlab."""
+
+    def __init__(self, cfg, slabs, comm, stream_ctx=None):
+        self.cfg, self.slabs, self.comm = cfg, slabs, comm
+        self.P = comm.nranks
+        nl = cfg.nlo
+        self.stream_ctx = stream_ctx  # context manager factory that makes torch's current stream the slab's stream
+        self.th_send = [s.new_buffer(s.th_len) for s in slabs]
+        self.th_gath = [s.new_buffer(s.th_len * self.P) for s in slabs]
+        self.th_gath2 = [s.new_buffer(s.th_len * self.P) for s in slabs]
+        self.x_send = [s.new_buffer(nl) for s in slabs]
+        self.x_gath = [s.new_buffer(nl * self.P) for s in slabs]
+        self.h_to_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
+        self.h_to_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
+        self.h_from_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
+        self.h_from_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
+        self.step_index = 1
+
+    def _comm(self, fn, *a):
+        if self.stream_ctx is None:
+            fn(*a)
+        else:
+            with self.stream_ctx():
+                fn(*a)
+
+    def step(self, s):
+        S, cm = self.slabs, self.comm
+        for x in S:
+            x.qgostep()
+            x.row_transform(0)
+        for i, x in enumerate(S):
+            x.thomas_phase(1, None, self.th_send[i])
+        self._comm(cm.all_gather, self.th_gath, self.th_send)
+        for i, x in enumerate(S):
+            x.thomas_phase(2, self.th_gath[i], self.th_send[i])
+        self._comm(cm.all_gather, self.th_gath2, self.th_send)
+        for i, x in enumerate(S):
+            x.thomas_phase(3, self.th_gath2[i], None)
+            x.row_transform(1)
+            x.xin_partial(self.x_send[i])
+        self._comm(cm.all_gather, self.x_gath, self.x_send)
+        for i, x in enumerate(S):
+            x.constr_partials(self.x_gath[i])
+            x.unpack(True)
+            x.halo_pack(self.h_to_lo[i], self.h_to_hi[i])
+        if self.P > 1:
+            self._comm(cm.halo_exchange, self.h_to_lo, self.h_to_hi, self.h_from_lo, self.h_from_hi)
+            for i, x in enumerate(S):
+                x.halo_unpack(self.h_from_lo[i], self.h_from_hi[i])
+        if (s - 1) % 25 == 0:
+            for x in S:
+                x.lf_average()
+
+    def steps(self, n, s0=None):
+        s0 = self.step_index if s0 is None else int(s0)
+        for s in range(s0, s0 + int(n)):
+            self.step(s)
+        self.step_index = s0 + int(n)
+
+    # helpers to scatter / gather global arrays (host side, for tests and set-up) --
+    def scatter_state(self, po, pom, qo, qom, wekpo, entoc, xon, scal):
+        nyg = self.cfg.nypo
+        for x in self.slabs:
+            sl = slab_slice(nyg, x.g0, x.g1)
+            x.set_state(po[:, sl, :], pom[:, sl, :], qo[:, sl, :], qom[:, sl, :])
+            x.set_forcing(wekpo[:, sl], entoc[:, sl], xon)
+            x.set_scalars(scal)
+
+    def gather_local(self):
+        """Owned rows of the local slabs: list of (g0, g1, [po, pom, qo, qom])."""
+        out = []
+        for x in self.slabs:
+            st = x.get_state()
+            out.append((x.g0, x.g1, [a[:, x.jlo - 1:x.jhi, :] for a in st]))
+        return out
+
+
+def global_consts(cfg, helmholtz):
+    """Start-up constants on the GLOBAL grid (numpy, init-only), as in OceanModel."""
+    A, rdm2, cl2m, cm2l = hostinit.eigmod(cfg.gpoc, cfg.hoc, cfg.fnot)
+    aoc, bd2 = hostinit.bd2oc(cfg)
+    hom = hostinit.homsol_box(cfg, rdm2, cm2l, bd2, helmholtz)
+    c = dict(amatoc=A, rdm2oc=rdm2, ctl2moc=cl2m, ctm2loc=cm2l, aoc=aoc, bd2oc=bd2, yporel=cfg.yporel(),
+             ddynoc=np.zeros((cfg.nxpo, cfg.nypo), order="F"))
+    c.update(hom)
+    return c

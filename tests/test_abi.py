@@ -31,9 +31,9 @@ def test_library_exports_all_symbols(repo_root):
 
 
 def test_params_struct_layout():
-    # 4 ints + 7 doubles + 4*MAXL + 3*MAXL^2 + MAXL + 1 doubles
+    # 4 ints + 7 doubles + 4*MAXL + 3*MAXL^2 + MAXL + 1 doubles + 2 ints
     n = lib.MAXL
-    assert ctypes.sizeof(lib.Params) == 4 * 4 + 8 * (7 + 4 * n + 3 * n * n + n + 1)
+    assert ctypes.sizeof(lib.Params) == 4 * 4 + 8 * (7 + 4 * n + 3 * n * n + n + 1) + 2 * 4
 
 
 def test_create_fails_loudly_without_gpu():

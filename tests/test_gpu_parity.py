@@ -185,6 +185,52 @@ def test_fast_dst_grid_vs_oracle():
         o.close()
 
 
+@pytest.mark.parametrize("name,nranks", [("box_small", 1), ("box_small", 2), ("box_med", 3), ("box_med", 4)])
+def test_y_slab_decomposition_on_one_gpu(name, nranks):
+    """The multi-GPU path with all slabs as virtual ranks on this one GPU: the slab
+    kernels (global-row boundary rules, phased Thomas, halo pack/unpack) and the
+    orchestration, against the single-domain oracle.  Only the transport differs
+    from a real multi-GPU run (torch.distributed is covered by the gloo CPU test)."""
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset(name)
+    o = make_oracle(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg, o.helmholtz)
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        pom = np.asfortranarray(0.99 * po)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        ent = np.asfortranarray(1e-7 * np.cos(np.arange(cfg.nxpo) / 5.0)[:, None] * np.ones(cfg.nypo)[None, :])
+        xon = np.zeros(cfg.nlo - 1)
+        xon[0] = 5e2
+        qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+        qom = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], pom)
+        scal = hostinit.constr(cfg, consts["amatoc"], po, pom)
+        o.set_p(po, pom)
+        o.set_forcing(wek, ent, xon)
+        parts = partition(cfg.nypo, nranks)
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
+        so.steps(30, s0=1)
+        o.steps(1, 30)
+        got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+        for g0, g1, fields in so.gather_local():
+            for dst, src in zip(got, fields):
+                dst[:, g0 - 1:g1, :] = src
+        for f, x, y in zip(FIELDS, got, o.get_state()):
+            assert relerr(x, y) < 1e-10, (f, nranks)
+        for sl in slabs:
+            assert np.array_equal(sl.get_scalars(), slabs[0].get_scalars())
+    finally:
+        for sl in slabs:
+            sl.close()
+        o.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json full size (NAtl 5 km, 961 x 961 x 3)
 # ---------------------------------------------------------------------------
