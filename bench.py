@@ -131,6 +131,72 @@ def pmc_traffic(kernel):
         return None
 
 
+def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
+    """N > 1: y-slab decomposition, one rank per GPU over RCCL (weak scaling).
+
+    Every rank owns a NAtl-5km-shaped slab (961 x ~960 rows x 3 layers) of a basin that
+    is `world` times taller (961 x (960*world+1)); the ranks exchange Thomas slab maps,
+    area-integral partials and halo rows every step (qgcm_hip.slab.SlabOcean).  The
+    reported value counts NAtl-5km-equivalent timesteps: world x (basin steps / s)."""
+    import dataclasses
+
+    import torch
+    import torch.distributed as dist
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import DistComm, HipSlab, SlabOcean, global_consts, partition, slab_slice
+
+    cfg = dataclasses.replace(cfg5, name="natl5_x%d" % world, nyaooc=cfg5.nyaooc * world, nyta=cfg5.nyta * world)
+    consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))  # init only, host
+    po = synth.gaussian_eddy(cfg)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+    scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+    g0, g1 = partition(cfg.nypo, world)[rank]
+    slab = HipSlab(cfg, consts, g0, g1, rank, world, device=local_rank)
+    # torch.distributed collectives are ordered on the library's own stream
+    torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
+    so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=True))
+    so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
+    so.steps(args.warmup, s0=1)
+    barrier()
+    t0 = time.perf_counter()
+    so.steps(args.steps, s0=args.warmup + 1)
+    barrier()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    (_, _, fields), = so.gather_local()
+    fin = torch.tensor([1.0 if all(np.isfinite(x).all() for x in fields) else 0.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    if rank == 0:
+        basin_sps = args.steps / wall
+        value = world * basin_sps
+        npts = cfg5.nxpo * cfg5.nypo
+        out = {
+            "metric": "ocean timesteps/sec (NAtl 5km 3-layer qgostep+ocinvq+ocqbdy)",
+            "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "NAtl 5km-shaped slab per GPU: 961 x %d x 3 basin (%d x taller), dto=540s, "
+                                   "Gaussian-eddy IC + double-gyre wind, oml off" % (cfg.nypo, world),
+                       "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
+                       "parallelism": "y-slabs over %d GPUs: all-gather of Thomas slab maps (x2), of area-integral "
+                                      "partials and of halo rows per step (RCCL)" % world,
+                       "value_counts": "NAtl-5km-equivalent timesteps = n_gpus x basin timesteps"},
+            "basin_steps_per_s": round(basin_sps, 2),
+            "model_years_per_day": round(cfg5.model_years_per_day(basin_sps), 1),
+            "state_finite": bool(fin.item() > 0.5),
+            "step_hbm_frac_per_gpu": round(56 * npts * 8.0 * basin_sps / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": None, "cpu_baseline": None,
+        }
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,21 +219,30 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # QGCM_BENCH_FORCE_SLABS=1 routes a 1-rank run through the y-slab code path (rehearsal of
+    # the multi-GPU plumbing on a one-GPU box; needs the torch.distributed.run environment)
+    force_slabs = os.environ.get("QGCM_BENCH_FORCE_SLABS") == "1"
+    if world > 1 or force_slabs:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from qgcm_hip import OceanModel, preset
     cfg = preset(WORKLOAD)
+
+    def barrier():
+        if world > 1 or force_slabs:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world > 1 or force_slabs:
+        run_slabs(args, world, rank, local_rank, cfg, real_stdout, barrier)
+        return
+
     po, wek = synthetic_inputs(cfg)
     model = OceanModel(cfg, device=local_rank)
     model.set_p(po, po)
     model.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     model.steps(args.warmup, s0=1)
     # 50 more untimed steps at the phase the timed region starts with, so that its
@@ -179,10 +254,6 @@ def main():
     ev_ms = model.time_steps(args.steps, s0=s_timed)  # HIP events on the library's stream
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
     state = model.get_state()
     finite = bool(all(np.isfinite(x).all() for x in state))
 
@@ -209,7 +280,7 @@ def main():
             "config": {"workload": "double_gyre_ocean_only NAtl 5km, 961x961x3 p-grid, dto=540s, "
                                    "Gaussian-eddy IC + double-gyre wind, oml off",
                        "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
-                       "parallelism": "single GPU" if world == 1 else "%d independent ensemble members (no domain decomposition yet)" % world},
+                       "parallelism": "single GPU"},
             "model_years_per_day": round(cfg.model_years_per_day(steps_per_s), 1),
             "hip_event_ms_per_step": round(ev_ms / args.steps, 5),
             "state_finite": finite,
@@ -224,12 +295,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             model.close()
             out["cpu_baseline"] = cpu_baseline(cfg, po, wek)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        real_stdout.write(json.dumps(out) + "\n")
-        real_stdout.flush()
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
 
 
 if __name__ == "__main__":

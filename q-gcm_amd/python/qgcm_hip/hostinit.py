@@ -227,3 +227,31 @@ def homsol_cyc(cfg, rdm2, bd2, yporel, helmholtz):
         out["hc1soc"][m], out["hc2soc"][m] = p1ys / det, p2ys / det
         out["hc1noc"][m], out["hc2noc"][m] = p1yn / det, p2yn / det
     return out
+
+
+def helmholtz_box_host(cfg, rhs, boc):
+    """Init-only host solve of the box Helmholtz problem (same algorithm as hsbxoc,
+    src/ocisubs.F:415-512: row DST-I, Thomas along y per wavenumber, row DST-I) with
+    scipy's DST-I (identical definition to FFTPACK dsint).  Used to build the
+    homogeneous solutions of the y-extended basins of the multi-GPU weak-scaling runs,
+    whose global row count exceeds what one handle solves; never on the per-step path."""
+    import scipy.fft
+    nx, ny = cfg.nxpo, cfg.nypo
+    aoc = 1.0 / (cfg.dyo * cfg.dyo)
+    ftnorm = 0.5 / cfg.nxto
+    w = scipy.fft.dst(np.asarray(rhs, dtype=np.float64)[1:-1, 1:-1], type=1, axis=0)  # (nk, ny-2)
+    b = np.asarray(boc, dtype=np.float64)[:nx - 2]
+    nr = ny - 2
+    gam = np.zeros((nx - 2, nr))
+    u = np.zeros((nx - 2, nr))
+    betinv = 1.0 / b
+    u[:, 0] = w[:, 0] * betinv
+    for r in range(1, nr):
+        gam[:, r] = aoc * betinv
+        betinv = 1.0 / (b - aoc * gam[:, r])
+        u[:, r] = (w[:, r] - aoc * u[:, r - 1]) * betinv
+    for r in range(nr - 2, -1, -1):
+        u[:, r] = u[:, r] - gam[:, r + 1] * u[:, r + 1]
+    out = np.zeros((nx, ny), order="F")
+    out[1:-1, 1:-1] = scipy.fft.dst(ftnorm * u, type=1, axis=0)
+    return out
