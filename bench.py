@@ -35,7 +35,7 @@ WORKLOAD = "natl5"
 # P5 unpack 14 (box).  "own" = what this implementation's kernel has to move
 # (rotating time-level buffers: no qom/pom rewrite, no po re-read) - DESIGN.md.
 ALGO_FIELDS = {"k_tend": (24, 21), "k_dst_fwd": (6, 6), "k_thomas": (6, 6), "k_dst_inv": (6, 6),
-               "k_unpack": (14, 8), "k_constr": (0, 0), "k_ocqbdy": (0, 0), "k_lf_average": (0, 0)}
+               "k_unpack": (14, 8), "k_constr": (0, 0), "k_cyc_bsums": (0, 0), "k_ocqbdy": (0, 0), "k_lf_average": (0, 0)}
 
 
 def divert_stdout():

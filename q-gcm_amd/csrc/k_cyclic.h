@@ -1,0 +1,254 @@
+// k_cyclic.h - zonally cyclic ocean (-Dcyclic_ocean): momentum-constraint pieces.
+//
+//  k_cyc_bsums   boundary line sums that qgostep/ocadif accumulate for the
+//                momentum constraints: Jacobian sums ajisoc/ajinoc
+//                (src/qgosubs.F:279-297, 404-423), third/fifth-derivative sums
+//                ap3/ap5 s/n oc (:429-443) and the bottom-drag sums bdrins/bdrinn
+//                (:150-163).  They use the state BEFORE the step.
+//  k_constr_cyc  ocinvq's constraint algebra (src/ocisubs.F:169-294): line
+//                integrals ayis/ayin of the new modal solutions, c1, c2, c3,
+//                dpioc update, ocncs/ocncn leapfrog.
+//  k_unpack_cyc  homogeneous corrections + modes->layers (src/ocisubs.F:300-327),
+//                optionally fused with ocqbdy (zonal boundaries only).
+#pragma once
+#include "qgcm_dev.h"
+
+struct QgCycSumParams {
+  QgGeom g;
+  const double *pom, *po, *qo; // state before the step
+  QgScalars *sc;
+  double bcfaco, dxom2, adfaco, fnot, dxo, dyo, delek_sgn; // delek_sgn = 0.5*sign(fnot)*delek
+  double ah2oc[QG_MAXL], ah4oc[QG_MAXL];
+};
+
+// periodic column index (1-based): columns 1..nxt are stored, column nx == column 1
+__device__ __forceinline__ int cyc_col(int i, int nxt) {
+  if (i < 1) i += nxt;
+  else if (i > nxt) i -= nxt;
+  return i;
+}
+
+// grid: (nl, 2): blockIdx.y = 0 south, 1 north.  256 threads, fixed-order tree.
+__global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
+  __shared__ double red[5][256];
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x, north = blockIdx.y;
+  const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt, ldx = P.g.ldx;
+  const long fs = P.g.fstride;
+  const double *pom = P.pom + fs * k, *p = P.po + fs * k, *q = P.qo + fs * k;
+  const double bcf = P.bcfaco, dxom2 = P.dxom2;
+  // rows counted from the boundary inwards: r = 0 boundary row, 1, 2, 3
+  auto row = [&](int r) { return north ? (ny - 1 - r) : r; }; // 0-based local row
+  auto PM = [&](int i, int r) { return pom[(long)row(r) * ldx + (cyc_col(i, nxt) - 1)]; };
+  // Del^2 of pom on rows r = 0 (boundary, mixed BC), 1, 2 (interior 5-point, cyclic in x)
+  auto D2 = [&](int i, int r) {
+    if (r == 0) return bcf * (PM(i, 1) - PM(i, 0));
+    return (PM(i, r - 1) + PM(i - 1, r) + PM(i + 1, r) + PM(i, r + 1) - 4.0 * PM(i, r)) * dxom2;
+  };
+  auto D4 = [&](int i, int r) { // r = 0 or 1
+    if (r == 0) return bcf * (D2(i, 1) - D2(i, 0));
+    return dxom2 * (D2(i, 0) + D2(i - 1, 1) + D2(i + 1, 1) + D2(i, 2) - 4.0 * D2(i, 1));
+  };
+  // note: for the northern boundary "r-1" is the row to the north, "r+1" to the south; the
+  // 5-point operator is symmetric so the value is the same, only the summation order of the
+  // two meridional neighbours differs from the reference (rounding level).
+  double s5 = 0.0, s9 = 0.0, s3 = 0.0, s5d = 0.0, sb = 0.0;
+  for (int i = 1 + tid; i <= nx; i += 256) {
+    // Jacobian sums: weights 0.5 at i = 1 and i = nx (the same point), 1 inside
+    const double wgt = (i == 1 || i == nx) ? 0.5 : 1.0;
+    const int ic = cyc_col(i, nxt);
+    const double dp = p[(long)row(1) * ldx + (cyc_col(ic + 1, nxt) - 1)] - p[(long)row(1) * ldx + (cyc_col(ic - 1, nxt) - 1)];
+    s5 += wgt * q[(long)row(0) * ldx + (ic - 1)] * dp;
+    s9 += wgt * q[(long)row(1) * ldx + (ic - 1)] * dp;
+    if (i <= nx - 1) {
+      s3 += D2(i, 1) - D2(i, 0);
+      s5d += D4(i, 1) - D4(i, 0);
+      if (k == P.g.nl - 1) sb += PM(i, 1) - PM(i, 0);
+    }
+  }
+  red[0][tid] = s5; red[1][tid] = s9; red[2][tid] = s3; red[3][tid] = s5d; red[4][tid] = sb;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off)
+      for (int v = 0; v < 5; ++v) red[v][tid] += red[v][tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    QgScalars *sc = P.sc;
+    // south: sums as written; north: the reference's sums carry the opposite sign
+    // (qgosubs.F:409-420 Jacobian with leading minus; :436,438 "boundary minus inner")
+    const double sg = north ? -1.0 : 1.0;
+    const double aj = P.dxo * P.dyo * (P.fnot * P.adfaco * (sg * red[0][0] + 2.0 * (sg * red[1][0])));
+    const double a3 = P.ah2oc[k] * (sg * red[2][0]);
+    const double a5 = P.ah4oc[k] * (sg * red[3][0]);
+    if (north) {
+      sc->ajinoc[k] = aj; sc->ap3noc[k] = a3; sc->ap5noc[k] = a5;
+      if (k == P.g.nl - 1) sc->bdrinn = P.delek_sgn * (sg * red[4][0]);
+    } else {
+      sc->ajisoc[k] = aj; sc->ap3soc[k] = a3; sc->ap5soc[k] = a5;
+      if (k == P.g.nl - 1) sc->bdrins = P.delek_sgn * red[4][0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct QgCycConstrParams {
+  QgGeom g;
+  const double *rowsum, *wrk;
+  QgScalars *sc;
+  QgConstr cs;
+  double dxo, dyo, tdto, fnot;
+  double gpoc[QG_MAXL], hoc[QG_MAXL];
+  double ctl2m[QG_MAXL * QG_MAXL], ctm2l[QG_MAXL * QG_MAXL];
+};
+
+template <int NL>
+__global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
+  const int lane = threadIdx.x;
+  const int ny = P.g.ny, nxt = P.g.nxt, ldw = P.g.ldw;
+  double s[NL], ys[NL], yn[NL];
+#pragma unroll
+  for (int m = 0; m < NL; ++m) s[m] = ys[m] = yn[m] = 0.0;
+  for (int j = P.g.jr0 - 1 + lane; j <= P.g.jr1 - 1; j += 64) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
+  }
+  // line integrals of the new modal solutions along rows 2 and nypo-1 (ocisubs.F:216-225):
+  // 0.5 w(1) + sum_{2..nx-1} + 0.5 w(nx) with w(nx) = w(1)  ==  sum over the nxto stored columns
+  for (int i = lane; i < nxt; i += 64) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+      ys[m] += P.wrk[P.g.wstride * m + (long)1 * ldw + i];
+      yn[m] -= P.wrk[P.g.wstride * m + (long)(ny - 2) * ldw + i];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+      s[m] += __shfl_xor(s[m], off);
+      ys[m] += __shfl_xor(ys[m], off);
+      yn[m] += __shfl_xor(yn[m], off);
+    }
+  }
+  if (lane != 0) return;
+  QgScalars *sc = P.sc;
+  const double fnot = P.fnot, tdto = P.tdto;
+  const double entfac = 0.5 * P.dyo * fnot * fnot;
+  double xin[NL], rhss[NL], rhsn[NL], ocsnew[NL], ocnnew[NL], clhss[NL], clhsn[NL];
+#pragma unroll
+  for (int m = 0; m < NL; ++m) {
+    xin[m] = s[m] * P.dxo * P.dyo;
+    sc->xinhom[m] = xin[m];
+  }
+  // ocisubs.F:176-193
+  rhss[0] = (entfac / P.hoc[0]) * sc->enisoc[0] + (fnot / P.hoc[0]) * sc->txisoc + sc->ajisoc[0] - sc->ap3soc[0] + sc->ap5soc[0];
+  rhsn[0] = (entfac / P.hoc[0]) * sc->eninoc[0] - (fnot / P.hoc[0]) * sc->txinoc + sc->ajinoc[0] + sc->ap3noc[0] - sc->ap5noc[0];
+#pragma unroll
+  for (int k = 1; k < NL - 1; ++k) {
+    rhss[k] = (entfac / P.hoc[k]) * (sc->enisoc[k] - sc->enisoc[k - 1]) + sc->ajisoc[k] - sc->ap3soc[k] + sc->ap5soc[k];
+    rhsn[k] = (entfac / P.hoc[k]) * (sc->eninoc[k] - sc->eninoc[k - 1]) + sc->ajinoc[k] + sc->ap3noc[k] - sc->ap5noc[k];
+  }
+  rhss[NL - 1] = -(entfac / P.hoc[NL - 1]) * sc->enisoc[NL - 2] + sc->ajisoc[NL - 1] - sc->ap3soc[NL - 1] + sc->ap5soc[NL - 1] +
+                 (fnot / P.hoc[NL - 1]) * sc->bdrins;
+  rhsn[NL - 1] = -(entfac / P.hoc[NL - 1]) * sc->eninoc[NL - 2] + sc->ajinoc[NL - 1] + sc->ap3noc[NL - 1] - sc->ap5noc[NL - 1] -
+                 (fnot / P.hoc[NL - 1]) * sc->bdrinn;
+  // ocisubs.F:199-206
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    ocsnew[k] = sc->ocncsp[k] + tdto * rhss[k];
+    ocnnew[k] = sc->ocncnp[k] + tdto * rhsn[k];
+    sc->ocncsp[k] = sc->ocncs[k];
+    sc->ocncnp[k] = sc->ocncn[k];
+    sc->ocncs[k] = ocsnew[k];
+    sc->ocncn[k] = ocnnew[k];
+  }
+  // ocisubs.F:212-234
+#pragma unroll
+  for (int m = 0; m < NL; ++m) {
+    double ayis = ys[m] * (P.dxo / P.dyo), ayin = yn[m] * (P.dxo / P.dyo);
+    double cs = 0.0, cn = 0.0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      cs = cs + P.ctl2m[k + NL * m] * ocsnew[k];
+      cn = cn + P.ctl2m[k + NL * m] * ocnnew[k];
+    }
+    clhss[m] = cs + ayis;
+    clhsn[m] = cn - ayin;
+  }
+  const double c3 = clhss[0] * P.cs.hbsioc;
+  double c1[NL], c2[NL], aipmod[NL], aiplay[NL];
+#pragma unroll
+  for (int m = 0; m < NL - 1; ++m) {
+    c1[m] = P.cs.hc2noc[m] * clhss[m + 1] - P.cs.hc2soc[m] * clhsn[m + 1];
+    c2[m] = P.cs.hc1soc[m] * clhsn[m + 1] - P.cs.hc1noc[m] * clhss[m + 1];
+    sc->c1[m] = c1[m];
+    sc->c2[m] = c2[m];
+  }
+  sc->c3 = c3;
+  aipmod[0] = xin[0] + c3 * P.cs.aipbho;
+#pragma unroll
+  for (int m = 1; m < NL; ++m) aipmod[m] = xin[m] + (c1[m - 1] + c2[m - 1]) * P.cs.aipcho[m - 1];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    double pl = 0.0;
+#pragma unroll
+    for (int m = 0; m < NL; ++m) pl = pl + P.ctm2l[m + NL * k] * aipmod[m];
+    aiplay[k] = pl;
+  }
+  // ocisubs.F:268-294 (the ermaso/emfroc monitors are diagnostics, not on this path)
+#pragma unroll
+  for (int k = 0; k < NL - 1; ++k) {
+    sc->dpiocp[k] = sc->dpioc[k];
+    sc->dpioc[k] = aiplay[k + 1] - aiplay[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// grid: (ceil(nx/256), ny)
+template <int NL, bool BDY>
+__global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, const QgBdyParams B) {
+  const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt;
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const int gj = blockIdx.y + 1;
+  if (gi > nx || gj > ny) return;
+  const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
+  const int ci = (gi > nxt) ? 0 : gi - 1; // column nx is column 1
+  auto point = [&](int jrow, double *pl) {
+    const bool inner = (jrow >= 2 && jrow <= ny - 1);
+    double pm[NL];
+    pm[0] = (inner ? P.wrk[(long)(jrow - 1) * P.g.ldw + ci] : 0.0) + P.sc->c3 * P.pbh[jrow - 1];
+#pragma unroll
+    for (int m = 1; m < NL; ++m) {
+      double wv = inner ? P.wrk[P.g.wstride * m + (long)(jrow - 1) * P.g.ldw + ci] : 0.0;
+      double homcor = P.sc->c1[m - 1] * P.pch1[(jrow - 1) + (long)ny * (m - 1)] + P.sc->c2[m - 1] * P.pch2[(jrow - 1) + (long)ny * (m - 1)];
+      pm[m] = wv + homcor;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < NL; ++m) v = v + P.ctm2l[m + NL * k] * pm[m];
+      pl[k] = v;
+    }
+  };
+  double pl[NL];
+  point(gj, pl);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) P.pnew[P.g.fstride * k + o] = pl[k];
+  if (BDY && (gj == 1 || gj == ny)) {
+    double pin[NL];
+    point(gj == 1 ? 2 : ny - 1, pin);
+    const double by = B.beta * B.yporel[gj - 1];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      double ap;
+      if (k == 0) ap = B.f0A[0] * pl[0] + B.f0A[NL] * pl[1];
+      else if (k == NL - 1) ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k];
+      else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
+      double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
+      if (k == NL - 1) q = q + B.ddynoc[o];
+      B.qo[P.g.fstride * k + o] = q;
+    }
+  }
+}

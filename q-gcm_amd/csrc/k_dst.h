@@ -247,3 +247,121 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// Cyclic ocean: real FFT rows, replacing FFTPACK drfftf / drfftb in hscyoc
+// (src/ocisubs.F:566-568, 601-605).  Two rows ride one complex FFT of length
+// N = nxto; the spectra are kept in FFTPACK's half-complex order
+//   r(1) = X_0, r(2k) = Re X_k, r(2k+1) = Im X_k, r(N) = X_{N/2}
+// so the reference's bd2oc ordering (src/q-gcm.F:935-943) applies unchanged.
+// INV = false: drfftf (forward, exp(-i..)).  INV = true: drfftb (unnormalised
+// inverse) by conjugation, plus the per-row sums needed by xintp and the
+// periodic copy wrk(nxpo,j) = wrk(1,j) is left to the consumers (column nxto
+// is simply not stored: consumers read column 1).
+// grid: (ceil(nrows/2), nlayers); dynamic LDS: 2*N cplx + 2*DST_NT doubles
+// ---------------------------------------------------------------------------
+template <bool INV>
+__global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int N = P.N, H = N / 2;
+  cplx *A = reinterpret_cast<cplx *>(smem_raw);
+  cplx *B = A + N;
+  double *red = reinterpret_cast<double *>(B + N);
+  const int tid = threadIdx.x;
+  const int ny = P.g.ny, ldw = P.g.ldw;
+  const int m = blockIdx.y;
+  const int ja = P.g.jr0 + 2 * blockIdx.x;
+  const bool has_b = (ja + 1 <= P.g.jr1);
+  double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
+  double *rowb = rowa + ldw;
+
+  if (!INV) {
+    for (int j = tid; j < N; j += DST_NT) A[j] = {rowa[j], has_b ? rowb[j] : 0.0};
+  } else {
+    // half-complex rows -> conj(Z), Z_k = Xa_k + i Xb_k
+    for (int k = tid; k <= H; k += DST_NT) {
+      double ar, ai, br, bi;
+      if (k == 0) {
+        ar = rowa[0]; ai = 0.0;
+        br = has_b ? rowb[0] : 0.0; bi = 0.0;
+      } else if (k == H) {
+        ar = rowa[N - 1]; ai = 0.0;
+        br = has_b ? rowb[N - 1] : 0.0; bi = 0.0;
+      } else {
+        ar = rowa[2 * k - 1]; ai = rowa[2 * k];
+        br = has_b ? rowb[2 * k - 1] : 0.0; bi = has_b ? rowb[2 * k] : 0.0;
+      }
+      A[k] = {ar - bi, -(ai + br)};
+      if (k > 0 && k < H) A[N - k] = {ar + bi, -(br - ai)};
+    }
+  }
+  __syncthreads();
+
+  cplx *in = A, *out = B;
+  int s = 1, len = N;
+  for (int f = 0; f < P.nfac; ++f) {
+    const int R = P.fac[f];
+    const int mm = len / R;
+    const int twstep = N / len;
+    switch (R) {
+      case 2: dst_stage<2>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 3: dst_stage<3>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 4: dst_stage<4>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 5: dst_stage<5>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      default: dst_stage_generic(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+    }
+    __syncthreads();
+    cplx *t = in;
+    in = out;
+    out = t;
+    s *= R;
+    len = mm;
+  }
+  const cplx *Z = in;
+
+  if (!INV) {
+    // Xa_k = (Z_k + conj Z_{N-k})/2, Xb_k = (Z_k - conj Z_{N-k})/(2i)
+    for (int k = tid; k <= H; k += DST_NT) {
+      cplx z1 = Z[k], z2 = Z[(N - k) % N];
+      double ar = 0.5 * (z1.x + z2.x), ai = 0.5 * (z1.y - z2.y);
+      double br = 0.5 * (z1.y + z2.y), bi = -0.5 * (z1.x - z2.x);
+      if (k == 0) {
+        rowa[0] = ar;
+        if (has_b) rowb[0] = br;
+      } else if (k == H) {
+        rowa[N - 1] = ar;
+        if (has_b) rowb[N - 1] = br;
+      } else {
+        rowa[2 * k - 1] = ar; rowa[2 * k] = ai;
+        if (has_b) { rowb[2 * k - 1] = br; rowb[2 * k] = bi; }
+      }
+    }
+  } else {
+    double rsa = 0.0, rsb = 0.0;
+    for (int j = tid; j < N; j += DST_NT) {
+      cplx z = Z[j];
+      rowa[j] = z.x;
+      rsa += z.x;
+      if (has_b) {
+        rowb[j] = -z.y;
+        rsb += -z.y;
+      }
+    }
+    if (P.rowsum) {
+      red[tid] = rsa;
+      red[DST_NT + tid] = rsb;
+      __syncthreads();
+      for (int off = DST_NT / 2; off > 0; off >>= 1) {
+        if (tid < off) {
+          red[tid] += red[tid + off];
+          red[DST_NT + tid] += red[DST_NT + tid + off];
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        P.rowsum[(long)m * ny + (ja - 1)] = red[0];
+        if (has_b) P.rowsum[(long)m * ny + ja] = red[DST_NT];
+      }
+    }
+  }
+}

@@ -17,6 +17,7 @@
 #include "k_dst64.h"
 #include "k_thomas.h"
 #include "k_misc.h"
+#include "k_cyclic.h"
 
 static thread_local char g_err[512] = "";
 
@@ -32,8 +33,8 @@ static thread_local char g_err[512] = "";
     if (e_ != hipSuccess) QG_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-enum { KN_TEND = 0, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_COUNT };
-static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_dst_fwd", "k_thomas", "k_dst_inv",
+enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_COUNT };
+static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_cyc_bsums", "k_dst_fwd", "k_thomas", "k_dst_inv",
                                              "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average"};
 
 struct qgcm_hip_ctx {
@@ -117,7 +118,6 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   *h = nullptr;
   if (prm->nlo < 2 || prm->nlo > QG_MAXL) QG_FAIL("qgcm_hip_create: nlo=%d outside 2..%d", prm->nlo, QG_MAXL);
   if (prm->nxpo < 4 || prm->nypo < 4) QG_FAIL("qgcm_hip_create: grid too small");
-  if (prm->cyclic) QG_FAIL("qgcm_hip_create: cyclic ocean not built yet");
   if (prm->nlo > 4) QG_FAIL("qgcm_hip_create: kernels are instantiated for nlo = 2, 3, 4");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -143,6 +143,7 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     g.jr0 = (g0 == 1) ? g.jlo + 1 : g.jlo;       // rows 2..nyg-1 of the global grid that this slab owns
     g.jr1 = (g1 == g.nyg) ? g.jhi - 1 : g.jhi;
     c->whole = (g0 == 1 && g1 == g.nyg);
+    if (prm->cyclic && !c->whole) QG_FAIL("qgcm_hip_create: y-slabs are implemented for the box ocean only");
   }
   g.nxt = g.nx - 1;
   g.nk = g.cyc ? g.nxt : g.nxt - 1;
@@ -274,6 +275,8 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
+  HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
+  HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   c->grid_set = true;
   return 0;
 }
@@ -318,10 +321,28 @@ extern "C" int qgcm_hip_set_homog_box(qgcm_hip_handle c, const double *ochom, co
   return 0;
 }
 
-extern "C" int qgcm_hip_set_homog_cyc(qgcm_hip_handle c, const double *, const double *, const double *, const double *,
-                                      const double *, const double *, const double *, const double *, double, double) {
-  (void)c;
-  QG_FAIL("qgcm_hip_set_homog_cyc: cyclic ocean not built yet");
+extern "C" int qgcm_hip_set_homog_cyc(qgcm_hip_handle c, const double *pch1oc, const double *pch2oc, const double *pbhoc,
+                                      const double *aipcho, const double *hc1soc, const double *hc2soc, const double *hc1noc,
+                                      const double *hc2noc, double hbsioc, double aipbho) {
+  if (!c || !pch1oc || !pch2oc || !pbhoc || !aipcho || !hc1soc || !hc2soc || !hc1noc || !hc2noc)
+    QG_FAIL("qgcm_hip_set_homog_cyc: null argument");
+  if (!c->g.cyc) QG_FAIL("qgcm_hip_set_homog_cyc: handle is a box ocean");
+  const QgGeom &g = c->g;
+  const int n1 = g.nl - 1;
+  HIPCHECK(hipMemcpy(c->pch1, pch1oc, sizeof(double) * g.ny * n1, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(c->pch2, pch2oc, sizeof(double) * g.ny * n1, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(c->pbh, pbhoc, sizeof(double) * g.ny, hipMemcpyHostToDevice));
+  for (int m = 0; m < n1; ++m) {
+    c->cs.aipcho[m] = aipcho[m];
+    c->cs.hc1soc[m] = hc1soc[m];
+    c->cs.hc2soc[m] = hc2soc[m];
+    c->cs.hc1noc[m] = hc1noc[m];
+    c->cs.hc2noc[m] = hc2noc[m];
+  }
+  c->cs.hbsioc = hbsioc;
+  c->cs.aipbho = aipbho;
+  c->homog_set = true;
+  return 0;
 }
 
 extern "C" int qgcm_hip_set_state(qgcm_hip_handle c, const double *po, const double *pom, const double *qo, const double *qom) {
@@ -358,9 +379,22 @@ extern "C" int qgcm_hip_set_forcing(qgcm_hip_handle c, const double *wekpo, cons
   return 0;
 }
 
-extern "C" int qgcm_hip_set_cyc_forcing(qgcm_hip_handle c, double, double, const double *, const double *) {
-  (void)c;
-  QG_FAIL("qgcm_hip_set_cyc_forcing: cyclic ocean not built yet");
+extern "C" int qgcm_hip_set_cyc_forcing(qgcm_hip_handle c, double txisoc, double txinoc, const double *enisoc,
+                                        const double *eninoc) {
+  if (!c) QG_FAIL("qgcm_hip_set_cyc_forcing: null handle");
+  if (!c->g.cyc) QG_FAIL("qgcm_hip_set_cyc_forcing: handle is a box ocean");
+  QgScalars h;
+  HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  h.txisoc = txisoc;
+  h.txinoc = txinoc;
+  for (int k = 0; k < c->g.nl - 1; ++k) {
+    if (enisoc) h.enisoc[k] = enisoc[k];
+    if (eninoc) h.eninoc[k] = eninoc[k];
+  }
+  HIPCHECK(hipMemcpyAsync(c->sc, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 extern "C" int qgcm_hip_set_scalars(qgcm_hip_handle c, const double *s) {
@@ -491,13 +525,35 @@ static int launch_tend(qgcm_hip_ctx *c) {
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
   const int ntiles = ((g.nx + TEND_TX - 1) / TEND_TX) * ((g.jhi - g.jlo + 1 + TEND_TY - 1) / TEND_TY);
   dim3 grid(8 * ((ntiles + 7) / 8)); // 1-D: the kernel maps blockIdx -> tile per XCD band
+  if (g.cyc) {
+    // boundary line sums for the momentum constraints, from the state before the step
+    QgCycSumParams S;
+    memset(&S, 0, sizeof(S));
+    S.g = g;
+    S.pom = P.pom; S.po = P.po; S.qo = P.qo;
+    S.sc = c->sc;
+    S.bcfaco = P.bcfaco; S.dxom2 = P.dxom2; S.adfaco = P.adfaco; S.fnot = pr.fnot;
+    S.dxo = pr.dxo; S.dyo = pr.dyo;
+    S.delek_sgn = 0.5 * (pr.fnot >= 0.0 ? 1.0 : -1.0) * pr.delek;
+    for (int k = 0; k < g.nl; ++k) {
+      S.ah2oc[k] = pr.ah2oc[k];
+      S.ah4oc[k] = pr.ah4oc[k];
+    }
+    KTimer tb(c, KN_BSUMS);
+    hipLaunchKernelGGL(k_cyc_bsums, dim3(g.nl, 2), dim3(256), 0, c->stream, S);
+    HIPCHECK(hipGetLastError());
+  }
   KTimer t(c, KN_TEND);
+#define QG_TEND(NLV)                                                                              \
+  if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true>), grid, dim3(TEND_NT), 0, c->stream, P);       \
+  else hipLaunchKernelGGL((k_tend<NLV, false>), grid, dim3(TEND_NT), 0, c->stream, P)
   switch (g.nl) {
-    case 2: hipLaunchKernelGGL((k_tend<2, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
-    case 3: hipLaunchKernelGGL((k_tend<3, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
-    case 4: hipLaunchKernelGGL((k_tend<4, false>), grid, dim3(TEND_NT), 0, c->stream, P); break;
+    case 2: QG_TEND(2); break;
+    case 3: QG_TEND(3); break;
+    case 4: QG_TEND(4); break;
     default: QG_FAIL("k_tend: unsupported nlo");
   }
+#undef QG_TEND
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -520,6 +576,12 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse) {
   dim3 grid(npairs, nlayers);
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF);
+  if (g.cyc) {
+    if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
+    else hipLaunchKernelGGL((k_rfft_cyc<false>), grid, dim3(DST_NT), c->dst_lds, c->stream, P);
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
   // wave-per-row-pair fast path when nxto = 64*M with an in-register M-point DFT available
   if (c->fftN == 64 * 15 && !c->force_generic_dst) {
     if (inverse) hipLaunchKernelGGL((k_dst64<15, true>), grid64, dim3(D64_NT), 0, c->stream, P);
@@ -575,6 +637,23 @@ static int launch_constr(qgcm_hip_ctx *c, const double *partials = nullptr, int 
   const QgGeom &g = c->g;
   QgConstrParams P;
   fill_constr_params(c, P);
+  if (g.cyc) {
+    QgCycConstrParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.g = g; Q.rowsum = c->rowsum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
+    Q.dxo = P.dxo; Q.dyo = P.dyo; Q.tdto = P.tdto; Q.fnot = P.fnot;
+    for (int k = 0; k < QG_MAXL; ++k) { Q.gpoc[k] = P.gpoc[k]; Q.hoc[k] = P.hoc[k]; }
+    for (int i = 0; i < QG_MAXL * QG_MAXL; ++i) { Q.ctl2m[i] = P.ctl2m[i]; Q.ctm2l[i] = P.ctm2l[i]; }
+    KTimer t(c, KN_CONSTR);
+    switch (g.nl) {
+      case 2: hipLaunchKernelGGL((k_constr_cyc<2>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      case 3: hipLaunchKernelGGL((k_constr_cyc<3>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      case 4: hipLaunchKernelGGL((k_constr_cyc<4>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      default: QG_FAIL("k_constr_cyc: unsupported nlo");
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
   P.partials = partials;
   P.npart = npart;
   KTimer t(c, KN_CONSTR);
@@ -626,7 +705,9 @@ static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
   dim3 grid((g.nx + 255) / 256, g.jhi - g.jlo + 1);
   KTimer t(c, KN_UNPACK);
 #define QG_UNPACK(NLV)                                                                                   \
-  if (fuse_bdy) hipLaunchKernelGGL((k_unpack_box<NLV, true>), grid, dim3(256), 0, c->stream, P, B);      \
+  if (g.cyc && fuse_bdy) hipLaunchKernelGGL((k_unpack_cyc<NLV, true>), grid, dim3(256), 0, c->stream, P, B);       \
+  else if (g.cyc) hipLaunchKernelGGL((k_unpack_cyc<NLV, false>), grid, dim3(256), 0, c->stream, P, B);             \
+  else if (fuse_bdy) hipLaunchKernelGGL((k_unpack_box<NLV, true>), grid, dim3(256), 0, c->stream, P, B); \
   else hipLaunchKernelGGL((k_unpack_box<NLV, false>), grid, dim3(256), 0, c->stream, P, B)
   switch (g.nl) {
     case 2: QG_UNPACK(2); break;
@@ -784,19 +865,24 @@ extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *
   HIPCHECK(hipMemcpyAsync(c->boc_tmp, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipMemcpyAsync(c->betc_tmp, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipStreamSynchronize(c->stream)); // the staging vectors die at scope exit
-  // interior columns i=2..nx-1 of every row -> wrk(c = i-2, j)
-  HIPCHECK(hipMemcpy2DAsync(c->wrk, (size_t)g.ldw * 8, wrk + 1, (size_t)g.nx * 8, (size_t)(g.nx - 2) * 8, (size_t)g.ny,
+  // box: interior columns i=2..nx-1 of every row -> wrk(c = i-2, j); cyclic: columns 1..nxto -> wrk(c = i-1, j)
+  const int coff = g.cyc ? 0 : 1;
+  HIPCHECK(hipMemcpy2DAsync(c->wrk, (size_t)g.ldw * 8, wrk + coff, (size_t)g.nx * 8, (size_t)g.nk * 8, (size_t)g.ny,
                             hipMemcpyHostToDevice, c->stream));
   if (launch_dst(c, c->wrk, 1, false)) return 1;
   if (launch_thomas(c, c->wrk, c->boc_tmp, c->betc_tmp, 1)) return 1;
   if (launch_dst(c, c->wrk, 1, true)) return 1;
-  HIPCHECK(hipMemcpy2DAsync(wrk + 1, (size_t)g.nx * 8, c->wrk, (size_t)g.ldw * 8, (size_t)(g.nx - 2) * 8, (size_t)g.ny,
+  HIPCHECK(hipMemcpy2DAsync(wrk + coff, (size_t)g.nx * 8, c->wrk, (size_t)g.ldw * 8, (size_t)g.nk * 8, (size_t)g.ny,
                             hipMemcpyDeviceToHost, c->stream));
   HIPCHECK(hipStreamSynchronize(c->stream));
-  // solid-boundary values are zero (src/ocisubs.F:496-509)
+  // box: solid-boundary values are zero (src/ocisubs.F:496-509); cyclic: E = W (:604)
   for (int j = 0; j < g.ny; ++j) {
-    wrk[(size_t)j * g.nx] = 0.0;
-    wrk[(size_t)j * g.nx + g.nx - 1] = 0.0;
+    if (g.cyc) {
+      wrk[(size_t)j * g.nx + g.nx - 1] = wrk[(size_t)j * g.nx];
+    } else {
+      wrk[(size_t)j * g.nx] = 0.0;
+      wrk[(size_t)j * g.nx + g.nx - 1] = 0.0;
+    }
   }
   for (int i = 0; i < g.nx; ++i) {
     wrk[i] = 0.0;

@@ -3,7 +3,7 @@ vectors of the true reference and against the CPU oracle.  Needs an MI355X."""
 import numpy as np
 import pytest
 
-from common import (BOX_NAMES, FIELDS, SNAPS, apply_inputs, load_golden, load_snapshot, make_oracle,
+from common import (BOX_NAMES, CONFIG_NAMES, FIELDS, SNAPS, apply_inputs, load_golden, load_snapshot, make_oracle,
                     preset, relerr, scal_err, state_errs)
 
 pytestmark = pytest.mark.gpu
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 # reference's association order, so they are required to be bit exact.
 TOL_CALL = 1e-12
 TOL_60 = 1e-10
-GPU_CONFIGS = BOX_NAMES
+GPU_CONFIGS = CONFIG_NAMES  # box and cyclic oceans
 
 
 @pytest.fixture(scope="module", params=GPU_CONFIGS)
@@ -43,6 +43,13 @@ def test_helmholtz_vs_reference(case):
 
 def test_homsol_products(case):
     cfg, g, m = case
+    if cfg.cyclic:
+        big = max(np.abs(g["h_hc1soc"]).max(), np.abs(g["h_hc2noc"]).max())
+        for k in ("pch1oc", "pch2oc", "pbhoc", "aipcho", "hbsioc", "aipbho"):
+            assert relerr(m.homog[k], g["h_" + k]) < 1e-12, k
+        for k in ("hc1soc", "hc2soc", "hc1noc", "hc2noc"):
+            assert np.abs(m.homog[k] - g["h_" + k]).max() / big < 1e-12, k
+        return
     for k in ("ochom", "aipohs", "cdiffo", "cdhoc"):
         assert relerr(m.homog[k], g["h_" + k]) < 1e-12, k
 
@@ -134,9 +141,13 @@ def test_random_state_vs_oracle(case):
         rng = np.random.default_rng(7)
         wek = np.asfortranarray(1e-6 * rng.standard_normal((cfg.nxpo, cfg.nypo)))
         ent = np.asfortranarray(1e-7 * rng.standard_normal((cfg.nxpo, cfg.nypo)))
+        if cfg.cyclic:  # forcing fields of a periodic channel are periodic
+            wek[-1, :], ent[-1, :] = wek[0, :], ent[0, :]
         for mod in (m, o):
             mod.set_p(po, pom)
             mod.set_forcing(wek, ent, np.full(cfg.nlo - 1, 5e2))
+            if cfg.cyclic:
+                mod.set_cyc_forcing(1.5e2, -0.5e2, np.full(cfg.nlo - 1, 1e-3), np.full(cfg.nlo - 1, -2e-3))
         m.steps(3, s0=5)
         o.steps(5, 3)
         for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
@@ -308,3 +319,35 @@ def test_full_size_long_run_is_finite_and_deterministic(natl5):
     # when there is no entrainment (src/ocisubs.F:342-345 with aient = 0)
     s = m.get_scalars()
     assert np.allclose(s[:cfg.nlo - 1], s[cfg.nlo - 1:2 * (cfg.nlo - 1)], rtol=0, atol=1e-6 * abs(s[0]) + 1e-3)
+
+
+def test_full_size_socn5_cyclic_vs_oracle():
+    """BASELINE configs[2]: Southern Ocean 5 km periodic channel, 4609 x 577 x 3
+    (nxto = 4608 = 2^9 3^2 real-FFT rows, 149 KB of LDS per row pair)."""
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("socn5")
+    m = OceanModel(cfg)
+    o = make_oracle(cfg)
+    try:
+        po = synth.gaussian_eddy(cfg, noise=1e-3)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        txis, txin = synth.tau_line_integrals(cfg, tx)
+        for mod in (m, o):
+            mod.set_p(po, po)
+            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+            mod.set_cyc_forcing(txis, txin)
+        m.steps(3, s0=1)
+        o.steps(1, 3)
+        for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
+            assert relerr(x, y) < TOL_CALL, f
+        sm, so = m.get_scalars(), o.get_scalars()
+        nl = cfg.nlo
+        scale = cfg.xlo * cfg.ylo * np.abs(po).max()
+        assert np.abs(sm[:2 * (nl - 1)] - so[:2 * (nl - 1)]).max() / scale < 1e-12
+        assert relerr(sm[2 * (nl - 1):], so[2 * (nl - 1):]) < 1e-10
+        m.steps(100, s0=4)  # exercises the graph path at this size
+        assert all(np.isfinite(x).all() for x in m.get_state())
+    finally:
+        m.close()
+        o.close()
