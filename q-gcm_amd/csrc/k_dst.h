@@ -114,7 +114,7 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
   double *red = reinterpret_cast<double *>(B + N); // 2*DST_NT doubles
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + P.layer0;
   const int ja = P.g.jr0 + 2 * blockIdx.x; // first row (1-based local j)
   const bool has_b = (ja + 1 <= P.g.jr1);
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
   double *red = reinterpret_cast<double *>(B + N);
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + P.layer0;
   const int ja = P.g.jr0 + 2 * blockIdx.x;
   const bool has_b = (ja + 1 <= P.g.jr1);
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int ny = P.g.ny, ldw = P.g.ldw;
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + P.layer0;
   const int pair = blockIdx.x * D64_WAVES + wv;
   const int ja = P.g.jr0 + 2 * pair;
   if (ja > P.g.jr1) return; // whole wave leaves; no workgroup barrier is ever used

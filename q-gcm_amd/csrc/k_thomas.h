@@ -61,7 +61,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const int lane = tid & 63, wv = tid >> 6;
   const int k = blockIdx.x * TH_KW + kk;
   const int kq = blockIdx.x * TH_KW + wv; // wavenumber whose chunk maps this wave scans
-  const int m = blockIdx.y;
+  const int m = blockIdx.y + P.layer0;
   const int nr = P.g.jr1 - P.g.jr0 + 1; // local rows jr0..jr1  <->  r = 0..nr-1
   const int ldw = P.g.ldw;
   const bool kok = k < P.g.nk;

@@ -75,6 +75,7 @@ struct QgDstParams {
   int nfac;
   int fac[QG_MAXFAC];
   int nlayers;            // layers to process (nl, or 1 for helmholtz())
+  int layer0;             // first layer (mode) of this launch
 };
 
 struct QgThomasParams {
@@ -86,7 +87,7 @@ struct QgThomasParams {
   const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index
   const double *betc; // (ldw, TH_NC, nlayers): pivot entering each chunk of rows
   double aoc, ftnorm;
-  int nlayers;
+  int nlayers, layer0;
 };
 
 struct QgUnpackParams {
