@@ -351,3 +351,40 @@ def test_full_size_socn5_cyclic_vs_oracle():
     finally:
         m.close()
         o.close()
+
+
+def test_full_size_natl1_slabs_vs_oracle():
+    """BASELINE configs[4]: NAtl 1 km (4801 x 4801 x 3) as y-slabs.  Four slabs run as
+    virtual ranks on this one GPU (the 8-GPU run only changes the transport); two
+    steps against the CPU oracle."""
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset("natl1")
+    nranks = 4
+    o = make_oracle(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))
+        po = synth.gaussian_eddy(cfg, noise=1e-3)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        zero2 = np.zeros((cfg.nxpo, cfg.nypo), order="F")
+        qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+        scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+        o.set_p(po, po)
+        o.set_forcing(wek, zero2, np.zeros(cfg.nlo - 1))
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True)
+                 for r, (g0, g1) in enumerate(partition(cfg.nypo, nranks))]
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.scatter_state(po, po, qo, qo, wek, zero2, np.zeros(cfg.nlo - 1), scal)
+        so.steps(2, s0=1)
+        o.steps(1, 2)
+        ref = o.get_state()
+        for g0, g1, fields in so.gather_local():
+            for f, x, y in zip(FIELDS, fields, ref):
+                assert relerr(x, y[:, g0 - 1:g1, :]) < 1e-11, (f, g0)
+    finally:
+        for sl in slabs:
+            sl.close()
+        o.close()
