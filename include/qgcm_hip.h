@@ -134,17 +134,16 @@ int qgcm_hip_helmholtz(qgcm_hip_handle h, double *wrk, const double *boc);
 
 /* ---- y-slab building blocks (multi-GPU; one handle per slab) -------------
  * A distributed step is: qgostep | row_transform(0) | thomas_phase 1, exchange,
- * 2, exchange, 3 | row_transform(1) | xin_partial, exchange | constr_partials |
+ * 2 | row_transform(1) | xin_partial, exchange | constr_partials |
  * unpack | halo_pack, exchange, halo_unpack.  All buffers named *_dev are DEVICE
  * pointers owned by the caller (e.g. torch tensors used with torch.distributed);
  * every call is asynchronous on the handle's stream. */
 int qgcm_hip_local_rows(qgcm_hip_handle h, int *nyl, int *joff, int *jlo, int *jhi);
 int qgcm_hip_row_transform(qgcm_hip_handle h, int inverse);
-/* number of doubles of one Thomas summary message: 2 * nlo * ldw */
+/* number of doubles of one Thomas summary message: 4 * nlo * ldw */
 int qgcm_hip_thomas_msg_len(qgcm_hip_handle h);
-/* phase 1: slab forward map -> send_dev.  phase 2: gath_dev = all ranks' phase-1
- * messages (rank-major) -> forward sweep, slab backward map -> send_dev.
- * phase 3: gath_dev = all ranks' phase-2 messages -> backward sweep. */
+/* phase 1: this slab's summary (4 numbers per wavenumber and mode) -> send_dev.
+ * phase 2: gath_dev = all ranks' phase-1 messages (rank-major) -> both sweeps finished. */
 int qgcm_hip_thomas_phase(qgcm_hip_handle h, int phase, const double *gath_dev, double *send_dev,
                           int rank, int nranks);
 /* local area-integral partials xin(nlo) -> send_dev (nlo doubles) */

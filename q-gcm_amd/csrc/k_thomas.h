@@ -19,12 +19,9 @@
 // maps are composed by a wave scan, and the sweep is re-run from the true
 // inflow - so each row is read once and written once (PHASE 0).
 //
-// y-slab decomposition (PHASE 1..3): the same idea one level up.  Each rank
-// reduces its slab to one affine map per wavenumber (phase 1), the maps are
-// all-gathered (nk*nl pairs of doubles instead of a transpose of the whole
-// array), the forward sweep is finished from the composed inflow and the
-// slab's backward map is produced (phase 2), a second all-gather, and the
-// backward sweep is finished (phase 3).
+// y-slab decomposition: the same idea one level up, see the PHASE list below: each
+// rank reduces its slab to four numbers per wavenumber, ONE all-gather of
+// 4*nk*nl doubles replaces the all-to-all transposes of the whole array.
 //
 // Algorithmic traffic: read w + write u (16 B per point) for PHASE 0.
 #pragma once
@@ -48,7 +45,19 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
   }
 }
 
-// message layout of one rank: pairs (C, D) at 2*(m*ldw + k)
+// PHASE 0  whole column in this handle: zero inflow at both ends, 1 read + 1 write.
+// y-slab decomposition (one exchange per step):
+//   u = u0 + uin*P,  v = B(u) + vin*Q  are linear in the values uin / vin that enter
+//   the slab from the ranks below / above, so a slab is summarised by
+//     Cf  = last value of the zero-inflow forward sweep,
+//     Cb  = first value of the zero-inflow backward sweep applied to u0,
+//     D   = product of (-a*bet) over the slab (forward AND backward gain),
+//     E   = first value of the backward sweep applied to the unit forward response P.
+//   D and E do not depend on the right-hand side (PHASE 4 computes them once).
+// PHASE 1  publish (Cf, D, Cb, E) per wavenumber; nothing is written to wrk.
+// PHASE 2  compose all ranks' summaries into uin and vin, finish both sweeps, write.
+// PHASE 4  set-up: D and E of this slab (input column = 0, unit inflow).
+// message layout of one rank: 4 doubles (Cf, D, Cb, E) at 4*(m*ldw + k)
 // grid: (ceil(nk/16), nlayers)
 template <int R, int PHASE>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
@@ -69,13 +78,14 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   double *wcol = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + k;
   const int r0 = c * R;
   const bool first_rows = (P.g.jr0 + P.g.joff == 2); // slab starts at the first interior row
-  const long msg = 2L * P.g.nl * ldw;
+  const long msg = 4L * P.g.nl * ldw;
+  const long mk = 4 * ((long)m * ldw + kq);
 
   double w[R], b[R];
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     int r = r0 + t;
-    bool ok = kok && r < nr;
+    bool ok = kok && r < nr && PHASE != 4;
     w[t] = ok ? wcol[(long)r * ldw] : 0.0;
   }
   // pivots of this chunk: betc = betinv of the row before the chunk (src/ocisubs.F:472-477)
@@ -94,64 +104,51 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
       b[t] = (kok && r < nr) ? betinv : 0.0;
     }
   }
-  double C, D;
-  if (PHASE != 3) {
-    // ---- forward: local affine map (zero inflow); rows past the slab are the identity
-    C = 0.0;
-    D = 1.0;
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      if (r0 + t < nr) {
-        C = (w[t] - a * C) * b[t];
-        D = -a * b[t] * D;
-      }
+  // values entering the slab from the other ranks
+  double uin = (PHASE == 4) ? 1.0 : 0.0, vin = 0.0;
+  if (PHASE == 2 && kq < P.g.nk) {
+    double u = 0.0;
+    for (int rk = 0; rk < P.rank; ++rk) u = P.gath[rk * msg + mk] + P.gath[rk * msg + mk + 1] * u;
+    uin = u;
+    double v = 0.0;
+    for (int s = P.nranks - 1; s > P.rank; --s) {
+      double us = uin; // value entering rank s: continue the forward chain from this rank
+      for (int t = P.rank; t < s; ++t) us = P.gath[t * msg + mk] + P.gath[t * msg + mk + 1] * us;
+      v = P.gath[s * msg + mk + 2] + P.gath[s * msg + mk + 3] * us + P.gath[s * msg + mk + 1] * v;
     }
-    sC[c][kk] = C;
-    sD[c][kk] = D;
-    __syncthreads();
-    double Cs = sC[lane][wv], Ds = sD[lane][wv];
-    affine_scan(Cs, Ds, lane);
-    if (PHASE == 1) {
-      // slab map = composition of all chunks: publish and stop
-      if (lane == 63 && kq < P.g.nk) {
-        P.send[2 * ((long)m * ldw + kq)] = Cs;
-        P.send[2 * ((long)m * ldw + kq) + 1] = Ds;
-      }
-      return;
-    }
-    // value entering the slab: compose the maps of the ranks before this one
-    double uin = 0.0;
-    if (PHASE == 2 && kq < P.g.nk) {
-      for (int rk = 0; rk < P.rank; ++rk) {
-        double Cr = P.gath[rk * msg + 2 * ((long)m * ldw + kq)];
-        double Dr = P.gath[rk * msg + 2 * ((long)m * ldw + kq) + 1];
-        uin = Cr + Dr * uin;
-      }
-    }
-    // value entering chunk `lane` = scanned map of chunk lane-1 applied to uin
-    {
-      double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
-      sIn[lane][wv] = (lane == 0) ? uin : Cprev + Dprev * uin;
-    }
-    __syncthreads();
-    double u = sIn[c][kk];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      if (r0 + t < nr) {
-        u = (w[t] - a * u) * b[t];
-        w[t] = u;
-      }
-    }
-    if (PHASE == 2) {
-      // the forward result is needed again after the second exchange
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        int r = r0 + t;
-        if (kok && r < nr) wcol[(long)r * ldw] = w[t];
-      }
-    }
-    __syncthreads(); // sC/sD/sIn are reused by the backward sweep
+    vin = v;
   }
+  // ---- forward: local affine maps (zero inflow); rows past the slab are the identity
+  double C = 0.0, D = 1.0;
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    if (r0 + t < nr) {
+      C = (w[t] - a * C) * b[t];
+      D = -a * b[t] * D;
+    }
+  }
+  sC[c][kk] = C;
+  sD[c][kk] = D;
+  __syncthreads();
+  double Cs = sC[lane][wv], Ds = sD[lane][wv];
+  affine_scan(Cs, Ds, lane);
+  // lane 63 holds the composition of all chunks: zero-inflow end value and slab gain
+  const double Cf_tot = __shfl(Cs, 63), D_tot = __shfl(Ds, 63);
+  {
+    // value entering chunk `lane` = scanned map of chunk lane-1 applied to uin
+    double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
+    sIn[lane][wv] = (lane == 0) ? uin : Cprev + Dprev * uin;
+  }
+  __syncthreads();
+  double u = sIn[c][kk];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    if (r0 + t < nr) {
+      u = (w[t] - a * u) * b[t];
+      w[t] = u;
+    }
+  }
+  __syncthreads(); // sC/sD/sIn are reused by the backward sweep
   // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
   C = 0.0;
   D = 1.0;
@@ -167,22 +164,22 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __syncthreads();
   // sweep order is last chunk first: lane l stands for chunk 63-l
   const int cr = 63 - lane;
-  double Cs = sC[cr][wv], Ds = sD[cr][wv];
+  Cs = sC[cr][wv];
+  Ds = sD[cr][wv];
   affine_scan(Cs, Ds, lane);
-  if (PHASE == 2) {
+  if (PHASE == 1 || PHASE == 4) {
     if (lane == 63 && kq < P.g.nk) {
-      P.send[2 * ((long)m * ldw + kq)] = Cs;
-      P.send[2 * ((long)m * ldw + kq) + 1] = Ds;
+      if (PHASE == 4) {
+        P.slabDE[2 * ((long)m * ldw + kq)] = D_tot; // gain of the slab
+        P.slabDE[2 * ((long)m * ldw + kq) + 1] = Cs; // E: backward image of the unit forward response
+      } else {
+        P.send[mk] = Cf_tot;
+        P.send[mk + 1] = P.slabDE[2 * ((long)m * ldw + kq)];
+        P.send[mk + 2] = Cs;
+        P.send[mk + 3] = P.slabDE[2 * ((long)m * ldw + kq) + 1];
+      }
     }
     return;
-  }
-  double vin = 0.0;
-  if (PHASE == 3 && kq < P.g.nk) {
-    for (int rk = P.nranks - 1; rk > P.rank; --rk) {
-      double Cr = P.gath[rk * msg + 2 * ((long)m * ldw + kq)];
-      double Dr = P.gath[rk * msg + 2 * ((long)m * ldw + kq) + 1];
-      vin = Cr + Dr * vin;
-    }
   }
   {
     double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);

@@ -82,6 +82,7 @@ struct QgThomasParams {
   QgGeom g;
   const double *gath; // distributed sweep: all ranks' slab maps (rank-major), else nullptr
   double *send;       // distributed sweep: this rank's slab map
+  double *slabDE;     // (2, ldw, nl): gain D and E of this slab (PHASE 4 writes, PHASE 1 reads)
   int rank, nranks;
   double *wrk;
   const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index

@@ -50,6 +50,7 @@ struct qgcm_hip_ctx {
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
   double *wrk, *rowsum;
   double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
+  double *slabDE;                          // y-slab summary constants (gain D, E) per (mode, wavenumber)
   int thR;                                 // rows per chunk of the Thomas kernel
   double *pch1, *pch2, *pbh;
   QgScalars *sc;
@@ -176,6 +177,7 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->wrk, W * g.nl)) return 1;
   if (dalloc(&c->boc, (size_t)g.ldw * g.nl) || dalloc(&c->betc, (size_t)g.ldw * TH_NC * g.nl)) return 1;
   if (dalloc(&c->boc_tmp, (size_t)g.ldw) || dalloc(&c->betc_tmp, (size_t)g.ldw * TH_NC)) return 1;
+  if (dalloc(&c->slabDE, (size_t)2 * g.ldw * g.nl)) return 1;
   if (dalloc(&c->rowsum, (size_t)g.ny * g.nl)) return 1;
   if (dalloc(&c->pch1, (size_t)g.ny * g.nl) || dalloc(&c->pch2, (size_t)g.ny * g.nl) || dalloc(&c->pbh, g.ny)) return 1;
   HIPCHECK(hipMalloc((void **)&c->sc, sizeof(QgScalars)));
@@ -201,7 +203,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   hipStreamSynchronize(c->stream);
   for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
-                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
+                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
@@ -246,6 +248,9 @@ static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* 
     }
   }
 }
+
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
+                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st);
 
 extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const double *bd2oc, const double *ddynoc) {
   if (!c || !yporel || !bd2oc) QG_FAIL("qgcm_hip_set_grid: null argument");
@@ -295,6 +300,9 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   c->grid_set = true;
+  // slab summary constants (gain and backward image of the unit response), once
+  if (launch_thomas(c, c->wrk, c->boc, c->betc, g.nl, 4, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  HIPCHECK(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -615,15 +623,15 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   return 0;
 }
 
-static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers,
-                         int phase = 0, const double *gath = nullptr, double *send = nullptr, int rank = 0, int nranks = 1,
-                         int layer0 = 0, hipStream_t st = nullptr) {
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
+                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st) {
   if (!st) st = c->stream;
   const QgGeom &g = c->g;
   QgThomasParams P;
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
+  P.slabDE = c->slabDE;
   P.wrk = wrk;
   P.boc = boc;
   P.betc = betc;
@@ -638,7 +646,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
     case 0: hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, st, P); break;        \
     case 1: hipLaunchKernelGGL((k_thomas<RV, 1>), grid, dim3(TH_NT), 0, st, P); break;        \
     case 2: hipLaunchKernelGGL((k_thomas<RV, 2>), grid, dim3(TH_NT), 0, st, P); break;        \
-    default: hipLaunchKernelGGL((k_thomas<RV, 3>), grid, dim3(TH_NT), 0, st, P); break;       \
+    default: hipLaunchKernelGGL((k_thomas<RV, 4>), grid, dim3(TH_NT), 0, st, P); break;       \
   }
   switch (c->thR) {
     case 1: QG_TH(1); break;
@@ -815,7 +823,7 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
     }
   } else {
     if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
-    if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl)) return 1;
+    if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
     if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
   }
   if (launch_constr(c)) return 1;
@@ -910,7 +918,7 @@ extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *
   HIPCHECK(hipMemcpy2DAsync(c->wrk, (size_t)g.ldw * 8, wrk + coff, (size_t)g.nx * 8, (size_t)g.nk * 8, (size_t)g.ny,
                             hipMemcpyHostToDevice, c->stream));
   if (launch_dst(c, c->wrk, 1, false)) return 1;
-  if (launch_thomas(c, c->wrk, c->boc_tmp, c->betc_tmp, 1)) return 1;
+  if (launch_thomas(c, c->wrk, c->boc_tmp, c->betc_tmp, 1, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   if (launch_dst(c, c->wrk, 1, true)) return 1;
   HIPCHECK(hipMemcpy2DAsync(wrk + coff, (size_t)g.nx * 8, c->wrk, (size_t)g.ldw * 8, (size_t)g.nk * 8, (size_t)g.ny,
                             hipMemcpyDeviceToHost, c->stream));
@@ -948,14 +956,15 @@ extern "C" int qgcm_hip_row_transform(qgcm_hip_handle c, int inverse) {
   return launch_dst(c, c->wrk, c->g.nl, inverse != 0);
 }
 
-extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? 2 * c->g.nl * c->g.ldw : 0; }
+extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? 4 * c->g.nl * c->g.ldw : 0; }
 
 extern "C" int qgcm_hip_thomas_phase(qgcm_hip_handle c, int phase, const double *gath_dev, double *send_dev, int rank,
                                      int nranks) {
   if (check_ready(c, "qgcm_hip_thomas_phase")) return 1;
-  if (phase < 1 || phase > 3) QG_FAIL("qgcm_hip_thomas_phase: phase must be 1, 2 or 3");
-  if ((phase != 3 && !send_dev) || (phase != 1 && !gath_dev)) QG_FAIL("qgcm_hip_thomas_phase: missing buffer");
-  return launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, phase, gath_dev, send_dev, rank, nranks);
+  if (phase < 1 || phase > 2) QG_FAIL("qgcm_hip_thomas_phase: phase must be 1 or 2");
+  if ((phase == 1 && !send_dev) || (phase == 2 && !gath_dev)) QG_FAIL("qgcm_hip_thomas_phase: missing buffer");
+  if (nranks > 64) QG_FAIL("qgcm_hip_thomas_phase: at most 64 slabs");
+  return launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, phase, gath_dev, send_dev, rank, nranks, 0, nullptr);
 }
 
 extern "C" int qgcm_hip_xin_partial(qgcm_hip_handle c, double *send_dev) {

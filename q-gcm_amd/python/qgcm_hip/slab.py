@@ -5,9 +5,9 @@ The reference is a single-process OpenMP code; this decomposition is new design
 never split, so the tendency kernel, the row transforms and the unpack stay local.
 Per ocean step the ranks exchange
 
-  * the slab summaries of the tridiagonal sweeps along y (two all-gathers of
-    2*nlo*nk doubles: the chunk-scan of k_thomas one level up, instead of an
-    all-to-all transpose of the whole work array),
+  * the slab summaries of the tridiagonal sweeps along y (ONE all-gather of
+    4*nlo*nk doubles: both sweeps are linear in the values entering a slab, see
+    k_thomas.h, instead of two all-to-all transposes of the whole work array),
   * the nlo partial area integrals (all-gather, summed in rank order so every rank
     gets bit-identical constraint coefficients),
   * halo rows of the new po (3 rows: del-6 of the lagged field) and qo (1 row).
@@ -266,7 +266,6 @@ class SlabOcean:
         self.stream_ctx = stream_ctx  # context manager factory that makes torch's current stream the slab's stream
         self.th_send = [s.new_buffer(s.th_len) for s in slabs]
         self.th_gath = [s.new_buffer(s.th_len * self.P) for s in slabs]
-        self.th_gath2 = [s.new_buffer(s.th_len * self.P) for s in slabs]
         self.x_send = [s.new_buffer(nl) for s in slabs]
         self.x_gath = [s.new_buffer(nl * self.P) for s in slabs]
         self.h_to_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
@@ -291,10 +290,7 @@ class SlabOcean:
             x.thomas_phase(1, None, self.th_send[i])
         self._comm(cm.all_gather, self.th_gath, self.th_send)
         for i, x in enumerate(S):
-            x.thomas_phase(2, self.th_gath[i], self.th_send[i])
-        self._comm(cm.all_gather, self.th_gath2, self.th_send)
-        for i, x in enumerate(S):
-            x.thomas_phase(3, self.th_gath2[i], None)
+            x.thomas_phase(2, self.th_gath[i], None)
             x.row_transform(1)
             x.xin_partial(self.x_send[i])
         self._comm(cm.all_gather, self.x_gath, self.x_send)

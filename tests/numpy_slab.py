@@ -33,7 +33,7 @@ class NumpySlab:
         # owned rows that are interior to the global domain (0-based local indices)
         self.r0 = self.jlo - 1 + (1 if g0 == 1 else 0)
         self.r1 = self.jhi - 1 - (1 if g1 == self.nyg else 0)
-        self.th_len = 2 * nl * self.nk
+        self.th_len = 4 * nl * self.nk
         self.halo_len = 4 * nl * nx
         # Thomas pivots of the slab rows (src/ocisubs.F:472-477), global recurrence
         rg0 = (self.r0 + 1 + self.joff) - 2
@@ -154,10 +154,9 @@ class NumpySlab:
             self.rowsum[:] = 0.0
             self.rowsum[r0:r1 + 1, :] = self.wrk[:, r0:r1 + 1, :].sum(axis=0)
 
-    def _slab_map_fwd(self, uin):
-        """forward sweep over the slab rows from inflow uin (nk, nl); returns u rows."""
+    def _fwd(self, w, uin):
+        """forward sweep over the slab rows from inflow uin (nk, nl)."""
         a = self.c["aoc"]
-        w = self.wrk[:, self.r0:self.r1 + 1, :]
         u = np.zeros_like(w)
         prev = uin
         for r in range(w.shape[1]):
@@ -165,46 +164,43 @@ class NumpySlab:
             u[:, r, :] = prev
         return u
 
-    def _pack(self, buf, Cm, Dm):
-        t = buf.numpy().reshape(self.cfg.nlo, self.nk, 2)
-        t[:, :, 0] = Cm.T
-        t[:, :, 1] = Dm.T
-
-    def _unpack(self, buf):
-        t = buf.numpy().reshape(self.nranks, self.cfg.nlo, self.nk, 2)
-        return t[..., 0].transpose(0, 2, 1), t[..., 1].transpose(0, 2, 1)  # (P, nk, nl)
+    def _bwd(self, u, vin):
+        a = self.c["aoc"]
+        v = np.zeros_like(u)
+        nxt = vin
+        for r in range(u.shape[1] - 1, -1, -1):
+            nxt = u[:, r, :] - a * self.bet[:, r, :] * nxt
+            v[:, r, :] = nxt
+        return v
 
     def thomas_phase(self, phase, gath, send):
+        """Same single-exchange protocol as k_thomas.h: a slab is summarised by
+        (Cf, D, Cb, E) per wavenumber and mode."""
         a = self.c["aoc"]
-        nl = self.cfg.nlo
-        Dprod = np.prod(-a * self.bet, axis=1)  # (nk, nl)
+        nl, nk = self.cfg.nlo, self.nk
+        z = np.zeros((nk, nl))
+        w = self.wrk[:, self.r0:self.r1 + 1, :]
         if phase == 1:
-            u = self._slab_map_fwd(np.zeros((self.nk, nl)))
-            self._pack(send, u[:, -1, :], Dprod)
-        elif phase == 2:
-            Cg, Dg = self._unpack(gath)
-            uin = np.zeros((self.nk, nl))
-            for r in range(self.rank):
-                uin = Cg[r] + Dg[r] * uin
-            u = self._slab_map_fwd(uin)
-            self.wrk[:, self.r0:self.r1 + 1, :] = u
-            v = np.zeros((self.nk, nl))
-            for r in range(u.shape[1] - 1, -1, -1):
-                v = u[:, r, :] - a * self.bet[:, r, :] * v
-            self._pack(send, v, Dprod)
-        else:
-            Cg, Dg = self._unpack(gath)
-            vin = np.zeros((self.nk, nl))
-            for r in range(self.nranks - 1, self.rank, -1):
-                vin = Cg[r] + Dg[r] * vin
-            u = self.wrk[:, self.r0:self.r1 + 1, :]
-            ft = 0.5 / (self.cfg.nxpo - 1)
-            v = vin
-            out = np.zeros_like(u)
-            for r in range(u.shape[1] - 1, -1, -1):
-                v = u[:, r, :] - a * self.bet[:, r, :] * v
-                out[:, r, :] = ft * v
-            self.wrk[:, self.r0:self.r1 + 1, :] = out
+            u0 = self._fwd(w, z)
+            v0 = self._bwd(u0, z)
+            unit = self._fwd(np.zeros_like(w), np.ones((nk, nl)))   # forward response to unit inflow
+            E = self._bwd(unit, z)[:, 0, :]
+            D = np.prod(-a * self.bet, axis=1)
+            t = send.numpy().reshape(nl, nk, 4)
+            t[:, :, 0], t[:, :, 1], t[:, :, 2], t[:, :, 3] = u0[:, -1, :].T, D.T, v0[:, 0, :].T, E.T
+            return
+        g = gath.numpy().reshape(self.nranks, nl, nk, 4).transpose(0, 2, 1, 3)  # (P, nk, nl, 4)
+        us = []
+        u = z
+        for r in range(self.nranks):
+            us.append(u)
+            u = g[r, :, :, 0] + g[r, :, :, 1] * u
+        v = z
+        for r in range(self.nranks - 1, self.rank, -1):
+            v = g[r, :, :, 2] + g[r, :, :, 3] * us[r] + g[r, :, :, 1] * v
+        uf = self._fwd(w, us[self.rank])
+        ft = 0.5 / (self.cfg.nxpo - 1)
+        self.wrk[:, self.r0:self.r1 + 1, :] = ft * self._bwd(uf, v)
 
     def xin_partial(self, send):
         send.numpy()[:] = self.rowsum.sum(axis=0)
