@@ -156,6 +156,14 @@ int qgcm_hip_halo_msg_len(qgcm_hip_handle h);
 int qgcm_hip_halo_pack(qgcm_hip_handle h, double *to_lower_dev, double *to_upper_dev);
 int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const double *from_upper_dev);
 
+/* One call per communication-free stage of a distributed step (fewer host round trips):
+ *   stage 1: qgostep, row_transform(0), thomas_phase(1)      a = Thomas send buffer
+ *   stage 2: thomas_phase(2), row_transform(1), xin_partial   a = Thomas gather buffer, b = xin send buffer
+ *   stage 3: constr_partials, unpack(+ocqbdy), halo_pack      a = xin gather buffer, b/c = halo to-lower/to-upper
+ *   stage 4: halo_unpack, optional lf_average (flags & 1)     a/b = halo from-lower/from-upper */
+int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_dev, double *c_dev,
+                        int rank, int nranks, int flags);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
  * the whole region, measured on the handle's stream. */

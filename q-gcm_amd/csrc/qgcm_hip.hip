@@ -1017,6 +1017,30 @@ extern "C" int qgcm_hip_halo_unpack(qgcm_hip_handle c, const double *from_lower_
   return 0;
 }
 
+extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, double *b, double *cc, int rank, int nranks,
+                                   int flags) {
+  switch (stage) {
+    case 1:
+      if (qgcm_hip_qgostep(c)) return 1;
+      if (qgcm_hip_row_transform(c, 0)) return 1;
+      return qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks);
+    case 2:
+      if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
+      if (qgcm_hip_row_transform(c, 1)) return 1;
+      return qgcm_hip_xin_partial(c, b);
+    case 3:
+      if (qgcm_hip_constr_partials(c, a, nranks)) return 1;
+      if (qgcm_hip_unpack(c, 1)) return 1;
+      if (nranks > 1) return qgcm_hip_halo_pack(c, b, cc);
+      return 0;
+    case 4:
+      if (nranks > 1 && qgcm_hip_halo_unpack(c, a, b)) return 1;
+      if (flags & 1) return qgcm_hip_lf_average(c);
+      return 0;
+    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..4");
+  }
+}
+
 extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) {
   if (check_ready(c, "qgcm_hip_time_steps")) return 1;
   hipEvent_t a, b;

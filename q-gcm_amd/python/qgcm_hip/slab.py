@@ -251,6 +251,11 @@ class HipSlab:
     def lf_average(self):
         check(self.L.qgcm_hip_lf_average(self.h)); self._done()
 
+    def stage(self, n, a=None, b=None, c=None, flags=0):
+        """One C call per communication-free stage (qgcm_hip_slab_stage)."""
+        check(self.L.qgcm_hip_slab_stage(self.h, int(n), self._ptr(a), self._ptr(b), self._ptr(c), self.rank, self.nranks, int(flags)))
+        self._done()
+
 
 # --------------------------------------------------------------------------
 # orchestration
@@ -283,28 +288,20 @@ class SlabOcean:
 
     def step(self, s):
         S, cm = self.slabs, self.comm
-        for x in S:
-            x.qgostep()
-            x.row_transform(0)
-        for i, x in enumerate(S):
-            x.thomas_phase(1, None, self.th_send[i])
+        for i, x in enumerate(S):  # tendency, forward row transform, slab summary of the y sweeps
+            x.stage(1, self.th_send[i])
         self._comm(cm.all_gather, self.th_gath, self.th_send)
-        for i, x in enumerate(S):
-            x.thomas_phase(2, self.th_gath[i], None)
-            x.row_transform(1)
-            x.xin_partial(self.x_send[i])
+        for i, x in enumerate(S):  # both sweeps, inverse row transform, area-integral partials
+            x.stage(2, self.th_gath[i], self.x_send[i])
         self._comm(cm.all_gather, self.x_gath, self.x_send)
-        for i, x in enumerate(S):
-            x.constr_partials(self.x_gath[i])
-            x.unpack(True)
-            x.halo_pack(self.h_to_lo[i], self.h_to_hi[i])
+        for i, x in enumerate(S):  # constraints, modes -> layers (+ boundary PV), halo rows out
+            x.stage(3, self.x_gath[i], self.h_to_lo[i], self.h_to_hi[i])
         if self.P > 1:
             self._comm(cm.halo_exchange, self.h_to_lo, self.h_to_hi, self.h_from_lo, self.h_from_hi)
-            for i, x in enumerate(S):
-                x.halo_unpack(self.h_from_lo[i], self.h_from_hi[i])
-        if (s - 1) % 25 == 0:
-            for x in S:
-                x.lf_average()
+        avg = 1 if (s - 1) % 25 == 0 else 0
+        if self.P > 1 or avg:
+            for i, x in enumerate(S):  # halo rows in, leapfrog averaging every 25th step
+                x.stage(4, self.h_from_lo[i], self.h_from_hi[i], None, avg)
 
     def steps(self, n, s0=None):
         s0 = self.step_index if s0 is None else int(s0)

@@ -291,6 +291,22 @@ class NumpySlab:
             self.po[:, prow:prow + 3, :] = t[:3 * nl * nx].reshape(nl, 3, nx).transpose(2, 1, 0)
             self.qo[:, qrow, :] = t[3 * nl * nx:].reshape(nl, nx).T
 
+    def stage(self, n, a=None, b=None, c=None, flags=0):
+        """Same stage split as qgcm_hip_slab_stage."""
+        if n == 1:
+            self.qgostep(); self.row_transform(0); self.thomas_phase(1, None, a)
+        elif n == 2:
+            self.thomas_phase(2, a, None); self.row_transform(1); self.xin_partial(b)
+        elif n == 3:
+            self.constr_partials(a); self.unpack(True)
+            if self.nranks > 1:
+                self.halo_pack(b, c)
+        else:
+            if self.nranks > 1:
+                self.halo_unpack(a, b)
+            if flags & 1:
+                self.lf_average()
+
     def lf_average(self):
         nl = self.cfg.nlo
         self.qo = 0.5 * (self.qo + self.qom)
