@@ -87,6 +87,7 @@ struct QgThomasParams {
   double *wrk;
   const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index
   const double *betc; // (ldw, TH_NC, nlayers): pivot entering each chunk of rows
+  const int *rconv;   // (ldw, nlayers): local row from which the pivot recurrence is bitwise stationary
   double aoc, ftnorm;
   int nlayers, layer0;
 };

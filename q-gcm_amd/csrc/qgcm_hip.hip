@@ -51,6 +51,7 @@ struct qgcm_hip_ctx {
   double *wrk, *rowsum;
   double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
   double *slabDE;                          // y-slab summary constants (gain D, E) per (mode, wavenumber)
+  int *rconv, *rconv_tmp;                  // row from which the Thomas pivots are stationary
   int thR;                                 // rows per chunk of the Thomas kernel
   double *pch1, *pch2, *pbh;
   QgScalars *sc;
@@ -178,6 +179,10 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->boc, (size_t)g.ldw * g.nl) || dalloc(&c->betc, (size_t)g.ldw * TH_NC * g.nl)) return 1;
   if (dalloc(&c->boc_tmp, (size_t)g.ldw) || dalloc(&c->betc_tmp, (size_t)g.ldw * TH_NC)) return 1;
   if (dalloc(&c->slabDE, (size_t)2 * g.ldw * g.nl)) return 1;
+  HIPCHECK(hipMalloc((void **)&c->rconv, sizeof(int) * g.ldw * g.nl));
+  HIPCHECK(hipMalloc((void **)&c->rconv_tmp, sizeof(int) * g.ldw));
+  HIPCHECK(hipMemset(c->rconv, 0, sizeof(int) * g.ldw * g.nl));
+  HIPCHECK(hipMemset(c->rconv_tmp, 0, sizeof(int) * g.ldw));
   if (dalloc(&c->rowsum, (size_t)g.ny * g.nl)) return 1;
   if (dalloc(&c->pch1, (size_t)g.ny * g.nl) || dalloc(&c->pch2, (size_t)g.ny * g.nl) || dalloc(&c->pbh, g.ny)) return 1;
   HIPCHECK(hipMalloc((void **)&c->sc, sizeof(QgScalars)));
@@ -208,6 +213,8 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
   hipFree(c->sc);
+  hipFree(c->rconv);
+  hipFree(c->rconv_tmp);
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->evpool) hipEventDestroy(e);
@@ -231,21 +238,27 @@ static int thomas_rows_per_chunk(int nrows) {
 // Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477; only the pivot
 // entering each chunk of R rows is kept (the kernel re-runs the recurrence).
 static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* per spectral index */,
-                       double *boc_out /* ldw */, double *betc /* TH_NC*ldw */) {
+                       double *boc_out /* ldw */, double *betc /* TH_NC*ldw */, int *rconv /* ldw */) {
   const int nr = g.jr1 - g.jr0 + 1;         // rows of this slab
   const int rg0 = g.jr0 + g.joff - 2;       // global interior-row index of the slab's first row
   for (int k = 0; k < g.nk; ++k) {
     boc_out[k] = boc[k];
     double betinv = 1.0 / boc[k]; // global interior row 0
+    int gconv = rg0 + nr;         // first global row whose pivot equals its predecessor's (bitwise)
     for (int rg = 0; rg < rg0 + nr; ++rg) {
       if (rg > 0) {
         double gam = aoc * betinv;
-        betinv = 1.0 / (boc[k] - aoc * gam);
+        double nb = 1.0 / (boc[k] - aoc * gam);
+        if (nb == betinv && gconv == rg0 + nr) gconv = rg;
+        betinv = nb;
       }
       // betinv is the pivot of global row rg; it enters the chunk that starts at local row rg+1-rg0
       const int rl = rg + 1 - rg0;
       if (rl >= 0 && rl % R == 0 && rl / R < TH_NC) betc[(size_t)(rl / R) * g.ldw + k] = betinv;
     }
+    // a chunk starting at local row r0 >= gconv - rg0 sees only the stationary pivot (= its betc entry)
+    int lc = gconv - rg0;
+    rconv[k] = lc < 0 ? 0 : lc;
   }
 }
 
@@ -265,10 +278,13 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   if (c->thR < 0) QG_FAIL("qgcm_hip_set_grid: %d rows per slab exceed the single-segment Thomas kernel (<= 2048)", g.jr1 - g.jr0 + 1);
   {
     std::vector<double> bocv((size_t)g.ldw * g.nl, 0.0), betc((size_t)g.ldw * TH_NC * g.nl, 0.0), boc(g.nk);
+    std::vector<int> rcv((size_t)g.ldw * g.nl, 0);
     for (int m = 0; m < g.nl; ++m) {
       for (int k = 0; k < g.nk; ++k) boc[k] = bd2oc[k] - c->prm.rdm2oc[m];
-      build_betc(g, c->thR, c->prm.aoc, boc.data(), bocv.data() + (size_t)g.ldw * m, betc.data() + (size_t)g.ldw * TH_NC * m);
+      build_betc(g, c->thR, c->prm.aoc, boc.data(), bocv.data() + (size_t)g.ldw * m, betc.data() + (size_t)g.ldw * TH_NC * m,
+                 rcv.data() + (size_t)g.ldw * m);
     }
+    HIPCHECK(hipMemcpy(c->rconv, rcv.data(), rcv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(c->boc, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(c->betc, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice));
   }
@@ -635,6 +651,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
   P.wrk = wrk;
   P.boc = boc;
   P.betc = betc;
+  P.rconv = (boc == c->boc_tmp) ? c->rconv_tmp : c->rconv;
   P.aoc = c->prm.aoc;
   P.ftnorm = g.cyc ? 1.0 / g.nxt : 0.5 / g.nxt; // src/ocisubs.F:440, 547
   P.nlayers = nlayers;
@@ -909,7 +926,9 @@ extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *
   const QgGeom &g = c->g;
   // pivots for this boc (box: boc(i-1) multiplies sine wavenumber i-1, src/ocisubs.F:470-478)
   std::vector<double> bocv((size_t)g.ldw, 0.0), betc((size_t)g.ldw * TH_NC, 0.0);
-  build_betc(g, c->thR, c->prm.aoc, boc, bocv.data(), betc.data());
+  std::vector<int> rcv((size_t)g.ldw, 0);
+  build_betc(g, c->thR, c->prm.aoc, boc, bocv.data(), betc.data(), rcv.data());
+  HIPCHECK(hipMemcpyAsync(c->rconv_tmp, rcv.data(), rcv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipMemcpyAsync(c->boc_tmp, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipMemcpyAsync(c->betc_tmp, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHECK(hipStreamSynchronize(c->stream)); // the staging vectors die at scope exit

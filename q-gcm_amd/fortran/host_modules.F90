@@ -31,6 +31,11 @@ module ochomog
   save
   double precision, allocatable :: ochom(:,:,:), aipohs(:), cdiffo(:,:), cdhoc(:,:)
   double precision, allocatable :: xon(:), dpioc(:), dpiocp(:)
+  ! cyclic ocean (same names as src/ochomog_data.F; used when the shim is built -Dcyclic_ocean)
+  double precision, allocatable :: pch1oc(:,:), pch2oc(:,:), pbhoc(:), aipcho(:), hc1soc(:), hc2soc(:), &
+                                   hc1noc(:), hc2noc(:), ocncs(:), ocncn(:), ocncsp(:), ocncnp(:), &
+                                   enisoc(:), eninoc(:)
+  double precision :: hbsioc, aipbho, txisoc, txinoc
 end module ochomog
 
 module ocstate

@@ -48,6 +48,19 @@ module qgcm_hip_iface
       type(c_ptr), value :: h
       real(c_double), intent(in) :: ochom(*), cdiffo(*), cdhoc(*)
     end function
+    integer(c_int) function qgcm_hip_set_homog_cyc(h, pch1oc, pch2oc, pbhoc, aipcho, hc1soc, hc2soc, hc1noc, hc2noc, &
+                                                   hbsioc, aipbho) bind(C, name='qgcm_hip_set_homog_cyc')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: pch1oc(*), pch2oc(*), pbhoc(*), aipcho(*), hc1soc(*), hc2soc(*), hc1noc(*), hc2noc(*)
+      real(c_double), value :: hbsioc, aipbho
+    end function
+    integer(c_int) function qgcm_hip_set_cyc_forcing(h, txisoc, txinoc, enisoc, eninoc) bind(C, name='qgcm_hip_set_cyc_forcing')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: txisoc, txinoc
+      real(c_double), intent(in) :: enisoc(*), eninoc(*)
+    end function
     integer(c_int) function qgcm_hip_set_state(h, po, pom, qo, qom) bind(C, name='qgcm_hip_set_state')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h

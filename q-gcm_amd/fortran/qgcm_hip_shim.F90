@@ -72,7 +72,10 @@ contains
     use ochomog
     if (homog_sent) return
     call qgcm_hip_ensure
-#ifndef cyclic_ocean
+#ifdef cyclic_ocean
+    call qgcm_hip_check(qgcm_hip_set_homog_cyc(qgcm_hip_handle, pch1oc, pch2oc, pbhoc, aipcho, hc1soc, hc2soc, &
+                                               hc1noc, hc2noc, hbsioc, aipbho), 'qgcm_hip_set_homog_cyc')
+#else
     call qgcm_hip_check(qgcm_hip_set_homog_box(qgcm_hip_handle, ochom, cdiffo, cdhoc), 'qgcm_hip_set_homog_box')
 #endif
     homog_sent = .true.
@@ -89,6 +92,12 @@ contains
     scal = 0.0d0
     scal(1:nlo-1) = dpioc
     scal(nlo:2*(nlo-1)) = dpiocp
+#ifdef cyclic_ocean
+    scal(2*(nlo-1)+1:2*(nlo-1)+nlo) = ocncs
+    scal(2*(nlo-1)+nlo+1:2*(nlo-1)+2*nlo) = ocncn
+    scal(2*(nlo-1)+2*nlo+1:2*(nlo-1)+3*nlo) = ocncsp
+    scal(2*(nlo-1)+3*nlo+1:2*(nlo-1)+4*nlo) = ocncnp
+#endif
     call qgcm_hip_check(qgcm_hip_set_scalars(qgcm_hip_handle, scal), 'qgcm_hip_set_scalars')
     call qgcm_hip_push_forcing
   end subroutine qgcm_hip_push
@@ -97,7 +106,19 @@ contains
     use ocstate, only : wekpo, entoc
     use ochomog, only : xon
     call qgcm_hip_check(qgcm_hip_set_forcing(qgcm_hip_handle, wekpo, entoc, xon), 'qgcm_hip_set_forcing')
+#ifdef cyclic_ocean
+    call push_cyc
+#endif
   end subroutine qgcm_hip_push_forcing
+
+#ifdef cyclic_ocean
+  ! line integrals that xforc (txisoc/txinoc) and oml (enisoc/eninoc) maintain, src/ochomog_data.F
+  subroutine push_cyc
+    use ochomog, only : txisoc, txinoc, enisoc, eninoc
+    call qgcm_hip_check(qgcm_hip_set_cyc_forcing(qgcm_hip_handle, txisoc, txinoc, enisoc, eninoc), &
+                        'qgcm_hip_set_cyc_forcing')
+  end subroutine push_cyc
+#endif
 
   ! device -> host module arrays (before valids, prsamp, monnc_comp, resave, ocnc_out ...)
   subroutine qgcm_hip_pull
@@ -109,6 +130,12 @@ contains
     call qgcm_hip_check(qgcm_hip_get_scalars(qgcm_hip_handle, scal), 'qgcm_hip_get_scalars')
     dpioc = scal(1:nlo-1)
     dpiocp = scal(nlo:2*(nlo-1))
+#ifdef cyclic_ocean
+    ocncs = scal(2*(nlo-1)+1:2*(nlo-1)+nlo)
+    ocncn = scal(2*(nlo-1)+nlo+1:2*(nlo-1)+2*nlo)
+    ocncsp = scal(2*(nlo-1)+2*nlo+1:2*(nlo-1)+3*nlo)
+    ocncnp = scal(2*(nlo-1)+3*nlo+1:2*(nlo-1)+4*nlo)
+#endif
   end subroutine qgcm_hip_pull
 
   subroutine qgcm_hip_shutdown
@@ -144,7 +171,9 @@ module ocisubs
   implicit none
   private
   public :: ocinvq, lwftoc, oftwrk, aoc, bd2oc
-#ifndef cyclic_ocean
+#ifdef cyclic_ocean
+  public :: hscyoc
+#else
   public :: hsbxoc
 #endif
 contains
@@ -154,7 +183,17 @@ contains
     call qgcm_hip_check(qgcm_hip_ocinvq(qgcm_hip_handle), 'ocinvq')
   end subroutine ocinvq
 
-#ifndef cyclic_ocean
+#ifdef cyclic_ocean
+  subroutine hscyoc (wrk, boc)
+    use parameters, only : nxpo, nypo, nxto
+    use qgcm_hip_iface
+    use qgcm_hip_state
+    double precision, intent(inout) :: wrk(nxpo,nypo)
+    double precision, intent(in) :: boc(nxto)
+    call qgcm_hip_ensure
+    call qgcm_hip_check(qgcm_hip_helmholtz(qgcm_hip_handle, wrk, boc), 'hscyoc')
+  end subroutine hscyoc
+#else
   subroutine hsbxoc (wrk, boc)
     use parameters, only : nxpo, nypo, nxto
     use qgcm_hip_iface

@@ -11,7 +11,8 @@ class QgcmHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.normpath(os.path.join(HERE, "..", "..", "lib", "libqgcm_hip.so"))
+    """In-tree build; QGCM_HIP_LIB overrides it (kernel experiments / ablation builds)."""
+    return os.environ.get("QGCM_HIP_LIB") or os.path.normpath(os.path.join(HERE, "..", "..", "lib", "libqgcm_hip.so"))
 
 
 class Params(C.Structure):
