@@ -86,7 +86,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   for (int t = 0; t < R; ++t) {
     int r = r0 + t;
     bool ok = kok && r < nr && PHASE != 4;
-    w[t] = ok ? wcol[r * ldw] : 0.0; // 32-bit row offsets: a slab is far below 2^31 doubles
+    w[t] = ok ? wcol[(long)r * ldw] : 0.0;
   }
   // pivots of this chunk: betc = betinv of the row before the chunk (src/ocisubs.F:472-477).
   // The recurrence reaches a bitwise fixed point after a few rows (median 15 at 5 km): from
@@ -127,9 +127,8 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     vin = v;
   }
   // ---- forward: local affine maps (zero inflow); rows past the slab are the identity
-  // PHASE 0: rows past the end have w = b = 0, which is harmless because nothing follows them
-  // and both inflows are zero; the slab phases must treat them as the identity map.
-  constexpr bool PRED = (PHASE != 0);
+  // rows past the end of the slab are the identity map
+  constexpr bool PRED = true; // measured: dropping the row predicate for PHASE 0 is slower (22.4 vs 20.0 us)
   double C = 0.0, D = 1.0;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
@@ -209,6 +208,6 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     int r = r0 + t;
-    if (kok && r < nr) wcol[r * ldw] = ft * w[t];
+    if (kok && r < nr) wcol[(long)r * ldw] = ft * w[t];
   }
 }
