@@ -183,8 +183,8 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             "config": {"workload": "NAtl 5km-shaped slab per GPU: 961 x %d x 3 basin (%d x taller), dto=540s, "
                                    "Gaussian-eddy IC + double-gyre wind, oml off" % (cfg.nypo, world),
                        "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
-                       "parallelism": "y-slabs over %d GPUs: all-gather of Thomas slab maps (x2), of area-integral "
-                                      "partials and of halo rows per step (RCCL)" % world,
+                       "parallelism": "y-slabs over %d GPUs: per step one all-gather each of the Thomas slab summaries, "
+                                      "the area-integral partials and the halo rows (RCCL)" % world,
                        "value_counts": "NAtl-5km-equivalent timesteps = n_gpus x basin timesteps"},
             "basin_steps_per_s": round(basin_sps, 2),
             "model_years_per_day": round(cfg5.model_years_per_day(basin_sps), 1),
@@ -218,6 +218,8 @@ def main():
                              % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if os.environ.get("QGCM_BENCH_SAME_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # QGCM_BENCH_FORCE_SLABS=1 routes a 1-rank run through the y-slab code path (rehearsal of
     # the multi-GPU plumbing on a one-GPU box; needs the torch.distributed.run environment)
@@ -225,7 +227,13 @@ def main():
     if world > 1 or force_slabs:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # QGCM_BENCH_BACKEND=gloo + QGCM_BENCH_SAME_GPU=1: rehearsal of the multi-rank code path with
+        # all ranks on one card (RCCL refuses duplicate devices); production is nccl = RCCL over xGMI
+        backend = os.environ.get("QGCM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from qgcm_hip import OceanModel, preset
     cfg = preset(WORKLOAD)
