@@ -16,9 +16,8 @@
 struct QgCycSumParams {
   QgGeom g;
   const double *pom, *po, *qo; // state before the step
-  QgScalars *sc;
-  double bcfaco, dxom2, adfaco, fnot, dxo, dyo, delek_sgn; // delek_sgn = 0.5*sign(fnot)*delek
-  double ah2oc[QG_MAXL], ah4oc[QG_MAXL];
+  double *part; // (5, BSUM_NB, 2, nl) partial line sums
+  double bcfaco, dxom2, adfaco, fnot, dxo, dyo;
 };
 
 // periodic column index (1-based): columns 1..nxt are stored, column nx == column 1
@@ -28,7 +27,11 @@ __device__ __forceinline__ int cyc_col(int i, int nxt) {
   return i;
 }
 
-// grid: (nl, 2): blockIdx.y = 0 south, 1 north.  256 threads, fixed-order tree.
+#define BSUM_NB 16 // blocks along x per (layer, side)
+
+// grid: (nl, 2, BSUM_NB): blockIdx.y = 0 south, 1 north; blockIdx.z = slice of columns.
+// 256 threads, fixed-order tree; the BSUM_NB partial sums per quantity are added, in block
+// order, by k_constr_cyc (deterministic).
 __global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
   __shared__ double red[5][256];
   const int tid = threadIdx.x;
@@ -53,7 +56,9 @@ __global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
   // 5-point operator is symmetric so the value is the same, only the summation order of the
   // two meridional neighbours differs from the reference (rounding level).
   double s5 = 0.0, s9 = 0.0, s3 = 0.0, s5d = 0.0, sb = 0.0;
-  for (int i = 1 + tid; i <= nx; i += 256) {
+  const int per = (nx + BSUM_NB - 1) / BSUM_NB;
+  const int ibeg = 1 + blockIdx.z * per, iend = min(nx, ibeg + per - 1);
+  for (int i = ibeg + tid; i <= iend; i += 256) {
     // Jacobian sums: weights 0.5 at i = 1 and i = nx (the same point), 1 inside
     const double wgt = (i == 1 || i == nx) ? 0.5 : 1.0;
     const int ic = cyc_col(i, nxt);
@@ -74,26 +79,17 @@ __global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
     __syncthreads();
   }
   if (tid == 0) {
-    QgScalars *sc = P.sc;
-    // south: sums as written; north: the reference's sums carry the opposite sign
-    // (qgosubs.F:409-420 Jacobian with leading minus; :436,438 "boundary minus inner")
-    const double sg = north ? -1.0 : 1.0;
-    const double aj = P.dxo * P.dyo * (P.fnot * P.adfaco * (sg * red[0][0] + 2.0 * (sg * red[1][0])));
-    const double a3 = P.ah2oc[k] * (sg * red[2][0]);
-    const double a5 = P.ah4oc[k] * (sg * red[3][0]);
-    if (north) {
-      sc->ajinoc[k] = aj; sc->ap3noc[k] = a3; sc->ap5noc[k] = a5;
-      if (k == P.g.nl - 1) sc->bdrinn = P.delek_sgn * (sg * red[4][0]);
-    } else {
-      sc->ajisoc[k] = aj; sc->ap3soc[k] = a3; sc->ap5soc[k] = a5;
-      if (k == P.g.nl - 1) sc->bdrins = P.delek_sgn * red[4][0];
-    }
+    double *o = P.part + (((long)k * 2 + north) * BSUM_NB + blockIdx.z) * 5;
+    for (int v = 0; v < 5; ++v) o[v] = red[v][0];
   }
 }
 
 // ---------------------------------------------------------------------------
 struct QgCycConstrParams {
   QgGeom g;
+  const double *bpart; // partial boundary line sums of k_cyc_bsums
+  double adfaco, delek_sgn; // 1/(12 dxo dyo f0); 0.5*sign(f0)*delek
+  double ah2oc[QG_MAXL], ah4oc[QG_MAXL];
   const double *rowsum, *wrk;
   QgScalars *sc;
   QgConstr cs;
@@ -105,7 +101,7 @@ struct QgCycConstrParams {
 template <int NL>
 __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
   const int lane = threadIdx.x;
-  const int ny = P.g.ny, nxt = P.g.nxt, ldw = P.g.ldw;
+  const int ny = P.g.ny;
   double s[NL], ys[NL], yn[NL];
 #pragma unroll
   for (int m = 0; m < NL; ++m) s[m] = ys[m] = yn[m] = 0.0;
@@ -113,28 +109,51 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
 #pragma unroll
     for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
   }
-  // line integrals of the new modal solutions along rows 2 and nypo-1 (ocisubs.F:216-225):
-  // 0.5 w(1) + sum_{2..nx-1} + 0.5 w(nx) with w(nx) = w(1)  ==  sum over the nxto stored columns
-  for (int i = lane; i < nxt; i += 64) {
-#pragma unroll
-    for (int m = 0; m < NL; ++m) {
-      ys[m] += P.wrk[P.g.wstride * m + (long)1 * ldw + i];
-      yn[m] -= P.wrk[P.g.wstride * m + (long)(ny - 2) * ldw + i];
-    }
-  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-    for (int m = 0; m < NL; ++m) {
-      s[m] += __shfl_xor(s[m], off);
-      ys[m] += __shfl_xor(ys[m], off);
-      yn[m] += __shfl_xor(yn[m], off);
-    }
+    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
   }
+  // line integrals of the new modal solutions along rows 2 and nypo-1 (ocisubs.F:216-225):
+  // 0.5 w(1) + sum_{2..nx-1} + 0.5 w(nx) with w(nx) = w(1) is the sum over the nxto stored
+  // columns, i.e. exactly the row sum the inverse transform already delivered
+#pragma unroll
+  for (int m = 0; m < NL; ++m) {
+    ys[m] = P.rowsum[(long)m * ny + 1];
+    yn[m] = -P.rowsum[(long)m * ny + (ny - 2)];
+  }
+  // boundary line sums of the previous qgostep: lane (5*(2k+side) + v) adds the BSUM_NB block
+  // partials of quantity v in block order (src/qgosubs.F:150-163, 279-297, 404-443)
+  double bs = 0.0;
+  if (lane < 10 * NL) {
+    const int ks = lane / 5, v = lane % 5;
+    for (int blk = 0; blk < BSUM_NB; ++blk) bs += P.bpart[((long)ks * BSUM_NB + blk) * 5 + v];
+  }
+  double bq[2 * NL][5];
+#pragma unroll
+  for (int ks = 0; ks < 2 * NL; ++ks)
+#pragma unroll
+    for (int v = 0; v < 5; ++v) bq[ks][v] = __shfl(bs, 5 * ks + v);
   if (lane != 0) return;
   QgScalars *sc = P.sc;
   const double fnot = P.fnot, tdto = P.tdto;
   const double entfac = 0.5 * P.dyo * fnot * fnot;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    // south: sums as written; north: the reference's sums carry the opposite sign
+    // (qgosubs.F:409-420 Jacobian with leading minus; :436,438 "boundary minus inner")
+    const double *S = bq[2 * k], *Nn = bq[2 * k + 1];
+    sc->ajisoc[k] = P.dxo * P.dyo * (fnot * P.adfaco * (S[0] + 2.0 * S[1]));
+    sc->ajinoc[k] = P.dxo * P.dyo * (fnot * P.adfaco * (-Nn[0] + 2.0 * (-Nn[1])));
+    sc->ap3soc[k] = P.ah2oc[k] * S[2];
+    sc->ap3noc[k] = P.ah2oc[k] * (-Nn[2]);
+    sc->ap5soc[k] = P.ah4oc[k] * S[3];
+    sc->ap5noc[k] = P.ah4oc[k] * (-Nn[3]);
+    if (k == NL - 1) {
+      sc->bdrins = P.delek_sgn * S[4];
+      sc->bdrinn = P.delek_sgn * (-Nn[4]);
+    }
+  }
   double xin[NL], rhss[NL], rhsn[NL], ocsnew[NL], ocnnew[NL], clhss[NL], clhsn[NL];
 #pragma unroll
   for (int m = 0; m < NL; ++m) {

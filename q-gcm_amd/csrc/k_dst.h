@@ -30,11 +30,11 @@ __device__ __forceinline__ cplx cmni(cplx a) { return {a.y, -a.x}; }
 
 // One Stockham DIF stage of radix R over the whole length-N sequence:
 //   a_r = in[q + s*(p + m*r)],  b_u = sum_r a_r w_R^{ru},  out[q + s*(R*p + u)] = b_u * w_len^{p*u}
-template <int R>
+template <int R, int NT = DST_NT>
 __device__ __forceinline__ void dst_stage(const cplx *__restrict__ in, cplx *__restrict__ out, int N, int s, int m,
                                           const double2 *__restrict__ tw, int twstep, int tid) {
   const int nb = m * s;
-  for (int b = tid; b < nb; b += DST_NT) {
+  for (int b = tid; b < nb; b += NT) {
     int p = b / s, q = b - p * s;
     cplx a[R];
 #pragma unroll
@@ -85,11 +85,12 @@ __device__ __forceinline__ void dst_stage(const cplx *__restrict__ in, cplx *__r
 }
 
 // generic odd prime radix (rare: only for grids whose nxto has a factor > 5)
+template <int NT = DST_NT>
 __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict__ in, cplx *__restrict__ out, int N,
                                                   int s, int m, const double2 *__restrict__ tw, int twstep, int tid) {
   const int nb = m * s;
   const int rstep = N / R;
-  for (int b = tid; b < nb; b += DST_NT) {
+  for (int b = tid; b < nb; b += NT) {
     int p = b / s, q = b - p * s;
     for (int u = 0; u < R; ++u) {
       cplx acc = {0.0, 0.0};
@@ -260,8 +261,10 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
 // is simply not stored: consumers read column 1).
 // grid: (ceil(nrows/2), nlayers); dynamic LDS: 2*N cplx + 2*DST_NT doubles
 // ---------------------------------------------------------------------------
+#define RFFT_NT 512
 template <bool INV>
-__global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
+__global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
+  constexpr int NT = RFFT_NT;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = P.N, H = N / 2;
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
@@ -276,10 +279,10 @@ __global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
   double *rowb = rowa + ldw;
 
   if (!INV) {
-    for (int j = tid; j < N; j += DST_NT) A[j] = {rowa[j], has_b ? rowb[j] : 0.0};
+    for (int j = tid; j < N; j += NT) A[j] = {rowa[j], has_b ? rowb[j] : 0.0};
   } else {
     // half-complex rows -> conj(Z), Z_k = Xa_k + i Xb_k
-    for (int k = tid; k <= H; k += DST_NT) {
+    for (int k = tid; k <= H; k += NT) {
       double ar, ai, br, bi;
       if (k == 0) {
         ar = rowa[0]; ai = 0.0;
@@ -304,11 +307,11 @@ __global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
     const int mm = len / R;
     const int twstep = N / len;
     switch (R) {
-      case 2: dst_stage<2>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 3: dst_stage<3>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 4: dst_stage<4>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 5: dst_stage<5>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      default: dst_stage_generic(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 2: dst_stage<2, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
     }
     __syncthreads();
     cplx *t = in;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
 
   if (!INV) {
     // Xa_k = (Z_k + conj Z_{N-k})/2, Xb_k = (Z_k - conj Z_{N-k})/(2i)
-    for (int k = tid; k <= H; k += DST_NT) {
+    for (int k = tid; k <= H; k += NT) {
       cplx z1 = Z[k], z2 = Z[(N - k) % N];
       double ar = 0.5 * (z1.x + z2.x), ai = 0.5 * (z1.y - z2.y);
       double br = 0.5 * (z1.y + z2.y), bi = -0.5 * (z1.x - z2.x);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
     }
   } else {
     double rsa = 0.0, rsb = 0.0;
-    for (int j = tid; j < N; j += DST_NT) {
+    for (int j = tid; j < N; j += NT) {
       cplx z = Z[j];
       rowa[j] = z.x;
       rsa += z.x;
@@ -349,18 +352,18 @@ __global__ __launch_bounds__(DST_NT) void k_rfft_cyc(const QgDstParams P) {
     }
     if (P.rowsum) {
       red[tid] = rsa;
-      red[DST_NT + tid] = rsb;
+      red[NT + tid] = rsb;
       __syncthreads();
-      for (int off = DST_NT / 2; off > 0; off >>= 1) {
+      for (int off = NT / 2; off > 0; off >>= 1) {
         if (tid < off) {
           red[tid] += red[tid + off];
-          red[DST_NT + tid] += red[DST_NT + tid + off];
+          red[NT + tid] += red[NT + tid + off];
         }
         __syncthreads();
       }
       if (tid == 0) {
         P.rowsum[(long)m * ny + (ja - 1)] = red[0];
-        if (has_b) P.rowsum[(long)m * ny + ja] = red[DST_NT];
+        if (has_b) P.rowsum[(long)m * ny + ja] = red[NT];
       }
     }
   }

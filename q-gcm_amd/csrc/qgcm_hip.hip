@@ -52,6 +52,7 @@ struct qgcm_hip_ctx {
   double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
   double *slabDE;                          // y-slab summary constants (gain D, E) per (mode, wavenumber)
   int *rconv, *rconv_tmp;                  // row from which the Thomas pivots are stationary
+  double *bpart;                           // cyclic: partial boundary line sums (k_cyc_bsums -> k_constr_cyc)
   int thR;                                 // rows per chunk of the Thomas kernel
   double *pch1, *pch2, *pbh;
   QgScalars *sc;
@@ -179,6 +180,7 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->boc, (size_t)g.ldw * g.nl) || dalloc(&c->betc, (size_t)g.ldw * TH_NC * g.nl)) return 1;
   if (dalloc(&c->boc_tmp, (size_t)g.ldw) || dalloc(&c->betc_tmp, (size_t)g.ldw * TH_NC)) return 1;
   if (dalloc(&c->slabDE, (size_t)2 * g.ldw * g.nl)) return 1;
+  if (dalloc(&c->bpart, (size_t)5 * BSUM_NB * 2 * g.nl)) return 1;
   HIPCHECK(hipMalloc((void **)&c->rconv, sizeof(int) * g.ldw * g.nl));
   HIPCHECK(hipMalloc((void **)&c->rconv_tmp, sizeof(int) * g.ldw));
   HIPCHECK(hipMemset(c->rconv, 0, sizeof(int) * g.ldw * g.nl));
@@ -208,7 +210,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   hipStreamSynchronize(c->stream);
   for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
-                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
+                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
@@ -309,7 +311,7 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipMalloc((void **)&c->sintab, sizeof(double) * st.size()));
   HIPCHECK(hipMemcpy(c->twid, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(c->sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
-  c->dst_lds = (size_t)2 * N * sizeof(cplx) + 2 * DST_NT * sizeof(double);
+  c->dst_lds = (size_t)2 * N * sizeof(cplx) + 2 * (g.cyc ? RFFT_NT : DST_NT) * sizeof(double);
   if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
@@ -573,16 +575,11 @@ static int launch_tend(qgcm_hip_ctx *c) {
     memset(&S, 0, sizeof(S));
     S.g = g;
     S.pom = P.pom; S.po = P.po; S.qo = P.qo;
-    S.sc = c->sc;
+    S.part = c->bpart;
     S.bcfaco = P.bcfaco; S.dxom2 = P.dxom2; S.adfaco = P.adfaco; S.fnot = pr.fnot;
     S.dxo = pr.dxo; S.dyo = pr.dyo;
-    S.delek_sgn = 0.5 * (pr.fnot >= 0.0 ? 1.0 : -1.0) * pr.delek;
-    for (int k = 0; k < g.nl; ++k) {
-      S.ah2oc[k] = pr.ah2oc[k];
-      S.ah4oc[k] = pr.ah4oc[k];
-    }
     KTimer tb(c, KN_BSUMS);
-    hipLaunchKernelGGL(k_cyc_bsums, dim3(g.nl, 2), dim3(256), 0, c->stream, S);
+    hipLaunchKernelGGL(k_cyc_bsums, dim3(g.nl, 2, BSUM_NB), dim3(256), 0, c->stream, S);
     HIPCHECK(hipGetLastError());
   }
   KTimer t(c, KN_TEND);
@@ -621,8 +618,8 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
   if (g.cyc) {
-    if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true>), grid, dim3(DST_NT), c->dst_lds, st, P);
-    else hipLaunchKernelGGL((k_rfft_cyc<false>), grid, dim3(DST_NT), c->dst_lds, st, P);
+    if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true>), grid, dim3(RFFT_NT), c->dst_lds, st, P);
+    else hipLaunchKernelGGL((k_rfft_cyc<false>), grid, dim3(RFFT_NT), c->dst_lds, st, P);
     HIPCHECK(hipGetLastError());
     return 0;
   }
@@ -686,9 +683,17 @@ static int launch_constr(qgcm_hip_ctx *c, const double *partials = nullptr, int 
   QgConstrParams P;
   fill_constr_params(c, P);
   if (g.cyc) {
+    const qgcm_hip_params &pr2 = c->prm;
     QgCycConstrParams Q;
     memset(&Q, 0, sizeof(Q));
     Q.g = g; Q.rowsum = c->rowsum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
+    Q.bpart = c->bpart;
+    Q.adfaco = 1.0 / (12.0 * pr2.dxo * pr2.dyo * pr2.fnot);
+    Q.delek_sgn = 0.5 * (pr2.fnot >= 0.0 ? 1.0 : -1.0) * pr2.delek;
+    for (int k = 0; k < g.nl; ++k) {
+      Q.ah2oc[k] = pr2.ah2oc[k];
+      Q.ah4oc[k] = pr2.ah4oc[k];
+    }
     Q.dxo = P.dxo; Q.dyo = P.dyo; Q.tdto = P.tdto; Q.fnot = P.fnot;
     for (int k = 0; k < QG_MAXL; ++k) { Q.gpoc[k] = P.gpoc[k]; Q.hoc[k] = P.hoc[k]; }
     for (int i = 0; i < QG_MAXL * QG_MAXL; ++i) { Q.ctl2m[i] = P.ctl2m[i]; Q.ctm2l[i] = P.ctm2l[i]; }
