@@ -33,9 +33,9 @@ static thread_local char g_err[512] = "";
     if (e_ != hipSuccess) QG_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_COUNT };
+enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_NOOP, KN_NOOP_TRAIN, KN_COUNT };
 static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_cyc_bsums", "k_dst_fwd", "k_thomas", "k_dst_inv",
-                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average"};
+                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average", "k_noop", "k_noop_train"};
 
 struct qgcm_hip_ctx {
   qgcm_hip_params prm;
@@ -65,6 +65,8 @@ struct qgcm_hip_ctx {
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
+  hipError_t timer_err = hipSuccess;
+  int timer_err_at = 0;
   bool profiling;
   hipEvent_t ev0, ev1;
   std::vector<hipEvent_t> evpool; // pairs, drained once per step (no host sync between kernels)
@@ -522,11 +524,18 @@ struct KTimer {
         c->evpool.push_back(b);
       }
       c->evkid.push_back(id);
-      (void)hipEventRecord(c->evpool[2 * slot], st);
+      note(hipEventRecord(c->evpool[2 * slot], st), 0);
     }
   }
   ~KTimer() {
-    if (c->profiling) (void)hipEventRecord(c->evpool[2 * slot + 1], st);
+    if (c->profiling)
+      note(hipEventRecord(c->evpool[2 * slot + 1], st), 1);
+  }
+  void note(hipError_t e, int which) {
+    if (e != hipSuccess && c->timer_err == hipSuccess) {
+      c->timer_err = e;
+      c->timer_err_at = 2 * (int)slot + which;
+    }
   }
 };
 
@@ -871,7 +880,12 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   if (ocinvq_impl(c, true)) return 1; // ocqbdy fused into the unpack kernel
   if ((s - 1) % 25 == 0)
     if (qgcm_hip_lf_average(c)) return 1;
-  if (c->profiling) drain_timers(c);
+  if (c->profiling) {
+    // an empty launch bracketed like the kernels (see qgcm_hip_profile_steps)
+    KTimer t(c, KN_NOOP);
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, c->stream);
+  }
+  if (c->evkid.size() > 4000) drain_timers(c); // bounds the event pool on long profiling runs
   return 0;
 }
 
@@ -1096,10 +1110,24 @@ extern "C" int qgcm_hip_profile_steps(qgcm_hip_handle c, int s0, int n, double *
   }
   HIPCHECK(hipStreamSynchronize(c->stream));
   c->profiling = true;
+  c->timer_err = hipSuccess;
+  // Calibration of the brackets. An event record is a packet of its own on the stream, so a
+  // bracket reads (kernel + its two records). "k_noop" is an empty launch bracketed like the
+  // kernels; "k_noop_train" is a long train of empty launches inside ONE bracket, i.e. what an
+  // empty launch costs on the stream by itself. Their difference is the cost of a bracket.
+  const int ntrain = 512;
+  {
+    KTimer t(c, KN_NOOP_TRAIN);
+    for (int i = 0; i < ntrain; ++i) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, c->stream);
+  }
+  // all brackets of the n steps are queued without a host synchronisation in between (the
+  // stream stays busy, as in the timed region) and read at the end
   int rc = qgcm_hip_steps(c, s0, n);
   drain_timers(c);
   c->profiling = false;
   if (rc) return 1;
+  if (c->timer_err != hipSuccess) QG_FAIL("qgcm_hip_profile_steps: event record failed: %s", hipGetErrorName(c->timer_err));
+  c->klaunch[KN_NOOP_TRAIN] = ntrain;
   for (int i = 0; i < KN_COUNT; ++i) {
     if (ms) ms[i] = c->kms[i];
     if (launches) launches[i] = c->klaunch[i];
