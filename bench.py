@@ -143,7 +143,8 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     import torch
     import torch.distributed as dist
     from qgcm_hip import hostinit, synth
-    from qgcm_hip.slab import DistComm, HipSlab, SlabOcean, global_consts, partition, slab_slice
+    from qgcm_hip.slab import (DistComm, HipSlab, SlabOcean, broadcast_unique_id, global_consts, partition,
+                               slab_slice)
 
     cfg = dataclasses.replace(cfg5, name="natl5_x%d" % world, nyaooc=cfg5.nyaooc * world, nyta=cfg5.nyta * world)
     consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))  # init only, host
@@ -157,7 +158,38 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     # torch.distributed collectives are ordered on the library's own stream
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=True))
-    so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
+    zero2, xon0 = np.zeros_like(wek), np.zeros(cfg.nlo - 1)
+
+    def local_state():
+        (_, _, fields), = so.gather_local()
+        return fields + [slab.get_scalars()]
+
+    # The exchanges are issued either by Python (torch.distributed between the four stage calls) or by the
+    # library itself (qgcm_hip_slab_steps: RCCL calls from C++ on the same stream).  The second keeps the host out
+    # of the step loop; it is used when its results are bitwise those of the first on every rank.
+    driver = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
+    if os.environ.get("QGCM_BENCH_EXCHANGES", "library") == "library" and dist.get_backend() == "nccl":
+        nver = 7
+        so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
+        so.steps(nver, s0=1)
+        ref = local_state()
+        so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
+        ok = 1.0
+        try:
+            so.use_library_exchanges(broadcast_unique_id(dist, slab.device))
+            so.steps(nver, s0=1)
+            got = local_state()
+            ok = 1.0 if all(np.array_equal(a, b) for a, b in zip(ref, got)) else 0.0
+        except Exception as e:  # noqa: BLE001 - any failure means: stay with the torch.distributed driver
+            print("library-issued exchanges unavailable: %r" % (e,), file=sys.stderr)
+            ok = 0.0
+        t = torch.tensor([ok], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if t.item() > 0.5:
+            driver = "library-issued RCCL (qgcm_hip_slab_steps), verified bitwise against the torch.distributed driver"
+        else:
+            so.native = False
+    so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
     so.steps(args.warmup, s0=1)
     barrier()
     t0 = time.perf_counter()
@@ -185,6 +217,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                        "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
                        "parallelism": "y-slabs over %d GPUs: per step one all-gather each of the Thomas slab summaries, "
                                       "the area-integral partials and the halo rows (RCCL)" % world,
+                       "exchange_driver": driver,
                        "value_counts": "NAtl-5km-equivalent timesteps = n_gpus x basin timesteps"},
             "basin_steps_per_s": round(basin_sps, 2),
             "model_years_per_day": round(cfg5.model_years_per_day(basin_sps), 1),

@@ -164,6 +164,24 @@ int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const 
 int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_dev, double *c_dev,
                         int rank, int nranks, int flags);
 
+/* The same distributed step with the exchanges issued by the library itself: RCCL calls on the
+ * handle's stream between the four stages, no host language in the loop. RCCL is bound at run
+ * time (dlopen), a single-GPU process never loads it.
+ *   qgcm_hip_comm_unique_id : rank 0 obtains the QGCM_HIP_COMM_ID_BYTES-byte rendezvous id and hands
+ *                             it to the other ranks by whatever the host has (MPI_Bcast, torch.distributed)
+ *   qgcm_hip_comm_init      : collective over the nranks handles (one process per GPU); rank r must own the
+ *                             r-th slab (slab_g0/slab_g1 of qgcm_hip_params); allocates the exchange buffers
+ *   qgcm_hip_slab_steps     : n whole steps from step s0 (collective). Per step: all-gather of the Thomas slab
+ *                             summaries (4*nlo*ldw doubles), all-gather of the nlo area-integral partials
+ *                             (added in rank order on every rank), edge rows (3 of po + 1 of qo per layer) to
+ *                             both neighbours as one all-gather, or as send/recv with QGCM_HIP_HALO_P2P=1.
+ *                             QGCM_HIP_SLAB_GRAPH=1 replays 50-step HIP graphs that contain the collectives.
+ * The communicator is released by qgcm_hip_destroy. */
+#define QGCM_HIP_COMM_ID_BYTES 128
+int qgcm_hip_comm_unique_id(char *id, int nbytes);
+int qgcm_hip_comm_init(qgcm_hip_handle h, const char *id, int nbytes, int rank, int nranks);
+int qgcm_hip_slab_steps(qgcm_hip_handle h, int s0, int n);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
  * the whole region, measured on the handle's stream. */

@@ -18,6 +18,7 @@
 #include "k_thomas.h"
 #include "k_misc.h"
 #include "k_cyclic.h"
+#include "slab_comm.h"
 
 static thread_local char g_err[512] = "";
 
@@ -75,6 +76,10 @@ struct qgcm_hip_ctx {
   int klaunch[KN_COUNT];
   // graphs keyed by (ip, iq, phase)
   std::map<int, hipGraphExec_t> graphs;
+  // y-slab exchanges over RCCL (qgcm_hip_comm_init); slab-step graphs keyed like `graphs`
+  QgSlabComm *sc_comm = nullptr;
+  std::map<int, hipGraphExec_t> slab_graphs;
+  bool slab_graph_mode = false; // QGCM_HIP_SLAB_GRAPH=1: capture 50 distributed steps (collectives included)
   size_t dst_lds;
 };
 
@@ -211,6 +216,15 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   if (!c) return 0;
   hipStreamSynchronize(c->stream);
   for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+  for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second);
+  if (c->sc_comm) {
+    QgSlabComm *m = c->sc_comm;
+    if (m->comm) m->api->CommDestroy(m->comm);
+    double *cb[] = {m->th_send, m->th_gath, m->x_send, m->x_gath, m->h_send, m->h_gath};
+    for (double *p : cb)
+      if (p) hipFree(p);
+    delete m;
+  }
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
                     c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
@@ -1077,6 +1091,151 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
       return 0;
     default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..4");
   }
+}
+
+// ---------------------------------------------------------------------------
+// y-slab steps with the exchanges issued from here (RCCL on the library's stream)
+// ---------------------------------------------------------------------------
+#define NCCLCHECK(m, expr)                                                                           \
+  do {                                                                                               \
+    ncclResult_t r_ = (expr);                                                                        \
+    if (r_ != ncclSuccess) QG_FAIL("%s failed: %s (%s:%d)", #expr, (m)->GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" int qgcm_hip_comm_unique_id(char *id, int nbytes) {
+  if (!id || nbytes < (int)sizeof(ncclUniqueId)) QG_FAIL("qgcm_hip_comm_unique_id: need a buffer of %d bytes", (int)sizeof(ncclUniqueId));
+  QgRccl *api = qg_rccl(g_err, sizeof(g_err));
+  if (!api) return 1;
+  ncclUniqueId u;
+  NCCLCHECK(api, api->GetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes, int rank, int nranks) {
+  if (check_ready(c, "qgcm_hip_comm_init")) return 1;
+  if (!id || nbytes < (int)sizeof(ncclUniqueId)) QG_FAIL("qgcm_hip_comm_init: need the %d-byte id of qgcm_hip_comm_unique_id", (int)sizeof(ncclUniqueId));
+  if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) QG_FAIL("qgcm_hip_comm_init: bad rank %d of %d (at most 64 slabs)", rank, nranks);
+  if (c->sc_comm) QG_FAIL("qgcm_hip_comm_init: this handle already has a communicator");
+  if (c->g.cyc) QG_FAIL("qgcm_hip_comm_init: y-slabs are implemented for the box ocean only");
+  const QgGeom &g = c->g;
+  // the slab must be the rank-th piece of the basin: first rank owns global row 1, last rank row nyg
+  if ((rank == 0) != (g.joff + g.jlo == 1) || (rank == nranks - 1) != (g.joff + g.jhi == g.nyg))
+    QG_FAIL("qgcm_hip_comm_init: slab rows %d..%d of %d do not fit rank %d of %d", g.joff + g.jlo, g.joff + g.jhi, g.nyg, rank, nranks);
+  QgRccl *api = qg_rccl(g_err, sizeof(g_err));
+  if (!api) return 1;
+  HIPCHECK(hipSetDevice(c->device));
+  QgSlabComm *m = new QgSlabComm;
+  m->api = api;
+  m->rank = rank;
+  m->nranks = nranks;
+  const char *hp = getenv("QGCM_HIP_HALO_P2P");
+  m->halo_p2p = hp && atoi(hp) != 0;
+  m->th_len = (size_t)4 * g.nl * g.ldw;
+  m->halo_len = (size_t)4 * g.nl * g.ldx;
+  c->sc_comm = m; // owned by the handle from here on (freed in qgcm_hip_destroy)
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  NCCLCHECK(api, api->CommInitRank(&m->comm, nranks, u, rank));
+  struct { double **p; size_t n; } bufs[] = {{&m->th_send, m->th_len}, {&m->th_gath, m->th_len * nranks},
+                                             {&m->x_send, (size_t)QG_MAXL}, {&m->x_gath, (size_t)QG_MAXL * nranks},
+                                             {&m->h_send, 2 * m->halo_len}, {&m->h_gath, 2 * m->halo_len * nranks}};
+  for (auto &b : bufs) {
+    HIPCHECK(hipMalloc((void **)b.p, b.n * sizeof(double)));
+    HIPCHECK(hipMemsetAsync(*b.p, 0, b.n * sizeof(double), c->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  const char *gm = getenv("QGCM_HIP_SLAB_GRAPH");
+  c->slab_graph_mode = gm && atoi(gm) != 0;
+  return 0;
+}
+
+// one distributed ocean step: four communication-free stages (the same calls SlabOcean.step makes through
+// qgcm_hip_slab_stage) and three exchanges, all ordered on c->stream; no host synchronisation
+static int slab_step(qgcm_hip_ctx *c, int s) {
+  QgSlabComm *m = c->sc_comm;
+  const int r = m->rank, P = m->nranks;
+  const int nl = c->g.nl;
+  const size_t n = m->halo_len;
+  // 1. tendency, forward row transform, slab summary of the two y sweeps
+  if (qgcm_hip_slab_stage(c, 1, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
+  NCCLCHECK(m->api, m->api->AllGather(m->th_send, m->th_gath, m->th_len, ncclDouble, m->comm, c->stream));
+  // 2. both sweeps from the composed inflows, inverse row transform, area-integral partials
+  if (qgcm_hip_slab_stage(c, 2, m->th_gath, m->x_send, nullptr, r, P, 0)) return 1;
+  NCCLCHECK(m->api, m->api->AllGather(m->x_send, m->x_gath, (size_t)nl, ncclDouble, m->comm, c->stream));
+  // 3. constraints (partials added in rank order on every rank), modes -> layers + boundary PV, edge rows out
+  double *to_lo = r > 0 ? m->h_send : nullptr, *to_hi = r < P - 1 ? m->h_send + n : nullptr;
+  if (qgcm_hip_slab_stage(c, 3, m->x_gath, to_lo, to_hi, r, P, 0)) return 1;
+  const double *from_lo = nullptr, *from_hi = nullptr;
+  if (P > 1) {
+    if (m->halo_p2p) {
+      // neighbours only; receive areas are the neighbour's slots of h_gath, as with the all-gather
+      double *rl = m->h_gath + (size_t)(2 * (r > 0 ? r - 1 : 0) + 1) * n, *rh = m->h_gath + (size_t)(2 * (r < P - 1 ? r + 1 : 0)) * n;
+      NCCLCHECK(m->api, m->api->GroupStart());
+      if (r > 0) {
+        NCCLCHECK(m->api, m->api->Send(to_lo, n, ncclDouble, r - 1, m->comm, c->stream));
+        NCCLCHECK(m->api, m->api->Recv(rl, n, ncclDouble, r - 1, m->comm, c->stream));
+      }
+      if (r < P - 1) {
+        NCCLCHECK(m->api, m->api->Send(to_hi, n, ncclDouble, r + 1, m->comm, c->stream));
+        NCCLCHECK(m->api, m->api->Recv(rh, n, ncclDouble, r + 1, m->comm, c->stream));
+      }
+      NCCLCHECK(m->api, m->api->GroupEnd());
+    } else {
+      NCCLCHECK(m->api, m->api->AllGather(m->h_send, m->h_gath, 2 * n, ncclDouble, m->comm, c->stream));
+    }
+    if (r > 0) from_lo = m->h_gath + (size_t)(2 * (r - 1) + 1) * n;  // what the lower neighbour sent upwards
+    if (r < P - 1) from_hi = m->h_gath + (size_t)(2 * (r + 1)) * n;  // what the upper neighbour sent downwards
+  }
+  // 4. edge rows in, leapfrog averaging after steps s with (s-1) mod 25 == 0
+  const int avg = (s - 1) % 25 == 0 ? 1 : 0;
+  if (P > 1 || avg)
+    if (qgcm_hip_slab_stage(c, 4, (double *)from_lo, (double *)from_hi, nullptr, r, P, avg)) return 1;
+  return 0;
+}
+
+static int get_slab_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
+  const int phase = (s0 - 1) % 25;
+  const int key = (c->ip << 16) | (c->iq << 8) | phase;
+  auto it = c->slab_graphs.find(key);
+  if (it != c->slab_graphs.end()) {
+    *out = it->second;
+    return 0;
+  }
+  const int ip0 = c->ip, iq0 = c->iq;
+  hipGraph_t graph;
+  HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int k = 0; k < kGraphBlock && !rc; ++k) rc = slab_step(c, s0 + k);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  c->ip = ip0; // nothing ran: the rotation state is that of the block's first step
+  c->iq = iq0;
+  if (rc) return 1;
+  HIPCHECK(e);
+  hipGraphExec_t exec;
+  HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  HIPCHECK(hipGraphDestroy(graph));
+  c->slab_graphs[key] = exec;
+  *out = exec;
+  return 0;
+}
+
+extern "C" int qgcm_hip_slab_steps(qgcm_hip_handle c, int s0, int n) {
+  if (check_ready(c, "qgcm_hip_slab_steps")) return 1;
+  if (!c->sc_comm) QG_FAIL("qgcm_hip_slab_steps: no communicator (qgcm_hip_comm_init)");
+  if (!c->homog_set) QG_FAIL("qgcm_hip_slab_steps: homogeneous solutions not set");
+  if (s0 < 1 || n < 0) QG_FAIL("qgcm_hip_slab_steps: bad step range");
+  int s = s0;
+  while (c->slab_graph_mode && n >= kGraphBlock) {
+    hipGraphExec_t ge;
+    if (get_slab_graph(c, s, &ge)) return 1;
+    HIPCHECK(hipGraphLaunch(ge, c->stream));
+    s += kGraphBlock; // 50 steps: both rotations are back where they started
+    n -= kGraphBlock;
+  }
+  for (; n > 0; --n, ++s)
+    if (slab_step(c, s)) return 1;
+  return 0;
 }
 
 extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) {

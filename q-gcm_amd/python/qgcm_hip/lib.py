@@ -41,6 +41,7 @@ SYMBOLS = [
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
     "qgcm_hip_xin_partial", "qgcm_hip_constr_partials", "qgcm_hip_unpack",
     "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack", "qgcm_hip_slab_stage",
+    "qgcm_hip_comm_unique_id", "qgcm_hip_comm_init", "qgcm_hip_slab_steps",
     "qgcm_hip_time_steps", "qgcm_hip_profile_steps", "qgcm_hip_copy_bandwidth", "qgcm_hip_stream",
 ]
 
@@ -88,6 +89,9 @@ def load_library():
     L.qgcm_hip_halo_pack.argtypes = [vp, vp, vp]
     L.qgcm_hip_halo_unpack.argtypes = [vp, vp, vp]
     L.qgcm_hip_slab_stage.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.qgcm_hip_comm_unique_id.argtypes = [C.c_char_p, C.c_int]
+    L.qgcm_hip_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.qgcm_hip_slab_steps.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_time_steps.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.qgcm_hip_profile_steps.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_int),
                                          C.POINTER(C.c_char_p), C.POINTER(C.c_int)]

@@ -131,6 +131,23 @@ class DistComm:
             from_hi[0].copy_(self._hgath[(2 * (r + 1)) * n:(2 * (r + 1) + 1) * n])
 
 
+def rccl_unique_id():
+    """The rendezvous id of qgcm_hip_comm_unique_id (call on rank 0, hand to every rank)."""
+    buf = C.create_string_buffer(128)
+    check(load_library().qgcm_hip_comm_unique_id(buf, 128))
+    return buf.raw
+
+
+def broadcast_unique_id(dist, device, group=None):
+    """rank 0 creates the id, torch.distributed carries it to the others."""
+    import torch
+    t = torch.zeros(128, dtype=torch.uint8, device=device)
+    if dist.get_rank(group) == 0:
+        t.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
+    dist.broadcast(t, src=0, group=group)
+    return bytes(t.cpu().numpy().tobytes())
+
+
 # --------------------------------------------------------------------------
 # one slab on one GPU through the C ABI
 # --------------------------------------------------------------------------
@@ -251,6 +268,16 @@ class HipSlab:
     def lf_average(self):
         check(self.L.qgcm_hip_lf_average(self.h)); self._done()
 
+    # exchanges issued by the library itself (RCCL on its own stream) ---------------
+    def comm_init(self, comm_id):
+        """Collective over all ranks' handles; comm_id = rccl_unique_id() of rank 0."""
+        check(self.L.qgcm_hip_comm_init(self.h, comm_id, len(comm_id), self.rank, self.nranks))
+        self.has_comm = True
+
+    def slab_steps(self, s0, n):
+        check(self.L.qgcm_hip_slab_steps(self.h, int(s0), int(n)))
+        self._done()
+
     def stage(self, n, a=None, b=None, c=None, flags=0):
         """One C call per communication-free stage (qgcm_hip_slab_stage)."""
         check(self.L.qgcm_hip_slab_stage(self.h, int(n), self._ptr(a), self._ptr(b), self._ptr(c), self.rank, self.nranks, int(flags)))
@@ -303,10 +330,20 @@ class SlabOcean:
             for i, x in enumerate(S):  # halo rows in, leapfrog averaging every 25th step
                 x.stage(4, self.h_from_lo[i], self.h_from_hi[i], None, avg)
 
+    def use_library_exchanges(self, comm_id):
+        """From now on steps() runs qgcm_hip_slab_steps: the library issues the RCCL exchanges
+        itself, Python is out of the step loop.  One slab per process; collective."""
+        assert len(self.slabs) == 1
+        self.slabs[0].comm_init(comm_id)
+        self.native = True
+
     def steps(self, n, s0=None):
         s0 = self.step_index if s0 is None else int(s0)
-        for s in range(s0, s0 + int(n)):
-            self.step(s)
+        if getattr(self, "native", False):
+            self.slabs[0].slab_steps(s0, n)
+        else:
+            for s in range(s0, s0 + int(n)):
+                self.step(s)
         self.step_index = s0 + int(n)
 
     # helpers to scatter / gather global arrays (host side, for tests and set-up) --

@@ -353,6 +353,48 @@ def test_full_size_socn5_cyclic_vs_oracle():
         o.close()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_library_issued_exchanges_one_rank(graph, monkeypatch):
+    """qgcm_hip_slab_steps: the distributed step with the RCCL exchanges issued by the library
+    itself, on a real (one-rank) RCCL communicator -- all a one-GPU box can hold; eager and as
+    50-step HIP graphs that contain the collectives.  Bitwise equal to the same slab kernels
+    driven stage by stage from Python (the path the virtual-rank tests pin to the oracle)."""
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, rccl_unique_id
+    monkeypatch.setenv("QGCM_HIP_SLAB_GRAPH", "1" if graph else "0")
+    cfg = preset("box_small")
+    o = make_oracle(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg, o.helmholtz)
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        zero2 = np.zeros((cfg.nxpo, cfg.nypo), order="F")
+        xon = np.zeros(cfg.nlo - 1)
+        qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+        scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+        out = []
+        for native in (False, True):
+            sl = HipSlab(cfg, consts, 1, cfg.nypo, 0, 1, sync_each_call=not native)
+            slabs.append(sl)
+            so = SlabOcean(cfg, [sl], LocalComm(1, after=torch.cuda.synchronize))
+            so.scatter_state(po, po, qo, qo, wek, zero2, xon, scal)
+            if native:
+                so.use_library_exchanges(rccl_unique_id())
+            so.steps(57, s0=1)   # graph mode: one 50-step block + 7 eager steps
+            sl.sync()
+            out.append((sl.get_state(), sl.get_scalars()))
+        for x, y in zip(out[0][0], out[1][0]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(out[0][1], out[1][1])
+    finally:
+        for sl in slabs:
+            sl.close()
+        o.close()
+
+
 def test_full_size_natl1_slabs_vs_oracle():
     """BASELINE configs[4]: NAtl 1 km (4801 x 4801 x 3) as y-slabs.  Four slabs run as
     virtual ranks on this one GPU (the 8-GPU run only changes the transport); two
