@@ -134,22 +134,23 @@ int qgcm_hip_helmholtz(qgcm_hip_handle h, double *wrk, const double *boc);
 
 /* ---- y-slab building blocks (multi-GPU; one handle per slab) -------------
  * A distributed step is: qgostep | row_transform(0) | thomas_phase 1, exchange,
- * 2 | row_transform(1) | xin_partial, exchange | constr_partials |
- * unpack | halo_pack, exchange, halo_unpack.  All buffers named *_dev are DEVICE
- * pointers owned by the caller (e.g. torch tensors used with torch.distributed);
- * every call is asynchronous on the handle's stream. */
+ * 2 | constr | row_transform(1) | unpack | halo_pack, exchange, halo_unpack.
+ * Two exchanges per step. All buffers named *_dev are DEVICE pointers owned by
+ * the caller (e.g. torch tensors used with torch.distributed); every call is
+ * asynchronous on the handle's stream. */
 int qgcm_hip_local_rows(qgcm_hip_handle h, int *nyl, int *joff, int *jlo, int *jhi);
 int qgcm_hip_row_transform(qgcm_hip_handle h, int inverse);
-/* number of doubles of one Thomas summary message: 4 * nlo * ldw */
+/* number of doubles of one slab summary message: 7 * nlo * ldw */
 int qgcm_hip_thomas_msg_len(qgcm_hip_handle h);
-/* phase 1: this slab's summary (4 numbers per wavenumber and mode) -> send_dev.
- * phase 2: gath_dev = all ranks' phase-1 messages (rank-major) -> both sweeps finished. */
+/* phase 1: this slab's summary of the two y sweeps -> send_dev: per mode and wavenumber the zero-inflow
+ *          end values of both sweeps, the gains, and the column sums that make up the area integrals
+ *          (xintp, src/ocisubs.F:160) - 7 numbers.
+ * phase 2: gath_dev = all ranks' phase-1 messages (rank-major) -> both sweeps finished, and the
+ *          basin-wide area integrals known on every rank (bitwise the same). */
 int qgcm_hip_thomas_phase(qgcm_hip_handle h, int phase, const double *gath_dev, double *send_dev,
                           int rank, int nranks);
-/* local area-integral partials xin(nlo) -> send_dev (nlo doubles) */
-int qgcm_hip_xin_partial(qgcm_hip_handle h, double *send_dev);
-/* gath_dev = all ranks' partials (rank-major, nlo each): sum in rank order + mass-constraint solve */
-int qgcm_hip_constr_partials(qgcm_hip_handle h, const double *gath_dev, int nranks);
+/* mass-constraint solve (src/ocisubs.F:329-370) from the area integrals thomas_phase 2 left behind */
+int qgcm_hip_constr(qgcm_hip_handle h);
 int qgcm_hip_unpack(qgcm_hip_handle h, int fuse_ocqbdy);
 /* halo messages: (3 rows of po + 1 row of qo) * nlo rows of ldx doubles each */
 int qgcm_hip_halo_msg_len(qgcm_hip_handle h);
@@ -157,10 +158,10 @@ int qgcm_hip_halo_pack(qgcm_hip_handle h, double *to_lower_dev, double *to_upper
 int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const double *from_upper_dev);
 
 /* One call per communication-free stage of a distributed step (fewer host round trips):
- *   stage 1: qgostep, row_transform(0), thomas_phase(1)      a = Thomas send buffer
- *   stage 2: thomas_phase(2), row_transform(1), xin_partial   a = Thomas gather buffer, b = xin send buffer
- *   stage 3: constr_partials, unpack(+ocqbdy), halo_pack      a = xin gather buffer, b/c = halo to-lower/to-upper
- *   stage 4: halo_unpack, optional lf_average (flags & 1)     a/b = halo from-lower/from-upper */
+ *   stage 1: qgostep, row_transform(0), thomas_phase(1)                          a = summary send buffer
+ *   stage 2: thomas_phase(2), constr, row_transform(1), unpack(+ocqbdy), halo_pack
+ *                                                      a = summary gather buffer, b/c = halo to-lower/to-upper
+ *   stage 3: halo_unpack, optional lf_average (flags & 1)                        a/b = halo from-lower/from-upper */
 int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_dev, double *c_dev,
                         int rank, int nranks, int flags);
 
@@ -171,9 +172,8 @@ int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_d
  *                             it to the other ranks by whatever the host has (MPI_Bcast, torch.distributed)
  *   qgcm_hip_comm_init      : collective over the nranks handles (one process per GPU); rank r must own the
  *                             r-th slab (slab_g0/slab_g1 of qgcm_hip_params); allocates the exchange buffers
- *   qgcm_hip_slab_steps     : n whole steps from step s0 (collective). Per step: all-gather of the Thomas slab
- *                             summaries (4*nlo*ldw doubles), all-gather of the nlo area-integral partials
- *                             (added in rank order on every rank), edge rows (3 of po + 1 of qo per layer) to
+ *   qgcm_hip_slab_steps     : n whole steps from step s0 (collective). Per step: all-gather of the slab
+ *                             summaries (7*nlo*ldw doubles) and the edge rows (3 of po + 1 of qo per layer) to
  *                             both neighbours as one all-gather, or as send/recv with QGCM_HIP_HALO_P2P=1.
  *                             QGCM_HIP_SLAB_GRAPH=1 replays 50-step HIP graphs that contain the collectives.
  * The communicator is released by qgcm_hip_destroy. */

@@ -46,28 +46,22 @@ __device__ inline double qg_block_sum(double v, double *red, int tid) {
 template <int NL>
 __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
   const int lane = threadIdx.x;
-  const int ny = P.g.ny;
   constexpr int n1 = NL - 1;
   double s[NL];
 #pragma unroll
   for (int m = 0; m < NL; ++m) s[m] = 0.0;
-  if (P.npart > 0) {
-    // y-slab run: the per-rank partial sums were all-gathered; add them in rank order
-    for (int r = 0; r < P.npart; ++r) {
+  // area integrals from the spectral column sums: xintp(wrk_m) = sum_k wcot(k) * ksum(m,k)
+  // (k_thomas.h); only odd wavenumbers (even 0-based index) contribute
+  for (int k = 2 * lane; k < P.g.nk; k += 128) {
+    const double wk = P.wcot[k];
 #pragma unroll
-      for (int m = 0; m < NL; ++m) s[m] += P.partials[r * NL + m];
-    }
-  } else {
-    for (int j = P.g.jr0 - 1 + lane; j <= P.g.jr1 - 1; j += 64) {
+    for (int m = 0; m < NL; ++m) s[m] += wk * P.ksum[(long)m * P.g.ldw + k];
+  }
+  // fixed-order butterfly: every lane ends with the same total
 #pragma unroll
-      for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
-    }
-    // fixed-order butterfly: every lane ends with the same total
+  for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
-    }
+    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
   }
   if (lane != 0) return;
   QgScalars *sc = P.sc;
@@ -147,29 +141,6 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
   }
 #pragma unroll
   for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
-}
-
-// y-slab run: this rank's share of the area integrals (row sums of its own rows)
-template <int NL>
-__global__ __launch_bounds__(64) void k_xin_partial(const QgConstrParams P, double *out) {
-  const int lane = threadIdx.x;
-  const int ny = P.g.ny;
-  double s[NL];
-#pragma unroll
-  for (int m = 0; m < NL; ++m) s[m] = 0.0;
-  for (int j = P.g.jr0 - 1 + lane; j <= P.g.jr1 - 1; j += 64) {
-#pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int m = 0; m < NL; ++m) out[m] = s[m];
-  }
 }
 
 // ---------------------------------------------------------------------------

@@ -54,11 +54,23 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 //     D   = product of (-a*bet) over the slab (forward AND backward gain),
 //     E   = first value of the backward sweep applied to the unit forward response P.
 //   D and E do not depend on the right-hand side (PHASE 4 computes them once).
-// PHASE 1  publish (Cf, D, Cb, E) per wavenumber; nothing is written to wrk.
-// PHASE 2  compose all ranks' summaries into uin and vin, finish both sweeps, write.
-// PHASE 4  set-up: D and E of this slab (input column = 0, unit inflow).
-// message layout of one rank: 4 doubles (Cf, D, Cb, E) at 4*(m*ldw + k)
+// Area integrals (xintp of the solution, src/ocisubs.F:160 + src/intsubs.f:78-133) are taken in
+// spectral space: the solution vanishes on the four walls, so xintp is the plain sum over the
+// interior, and the sum over i of sin(k i pi/n) is cot(k pi/2n) for odd k, 0 for even k. Hence
+//     xintp(wrk_m) = sum_k wcot(k) * ksum(m,k),   ksum(m,k) = ftnorm * sum_j v_j(k),
+// and ksum is a by-product of the backward sweep (no pass over the transformed field, and the
+// constraint solve no longer waits for the inverse row transform).  For y-slabs the column sum is
+// linear in the inflows too:  sum_j v_j = S0 + uin*SP + vin*SQ  (S0: zero-inflow sum, SP / SQ:
+// sums of the unit responses, right-hand-side independent), so every rank forms the basin-wide
+// ksum from the one all-gather of the slab summaries - bitwise the same on every rank.
+// PHASE 1  publish (Cf, D, Cb, E, S0, SP, SQ) per wavenumber; nothing is written to wrk.
+// PHASE 2  compose all ranks' summaries into uin, vin and the basin-wide ksum (lanes = ranks,
+//          two affine scans), finish both sweeps, write.
+// PHASE 4  set-up: D, E and SP of this slab (input column = 0, unit inflow from below).
+// PHASE 5  set-up: SQ (input column = 0, unit inflow from above).
+// message layout of one rank: TH_MSG doubles at TH_MSG*(m*ldw + k)
 // grid: (ceil(nk/16), nlayers)
+#define TH_MSG 7
 template <int R, int PHASE>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __shared__ double sC[TH_NC][TH_KW];
@@ -78,14 +90,15 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   double *wcol = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + k;
   const int r0 = c * R;
   const bool first_rows = (P.g.jr0 + P.g.joff == 2); // slab starts at the first interior row
-  const long msg = 4L * P.g.nl * ldw;
-  const long mk = 4 * ((long)m * ldw + kq);
+  const long msg = (long)TH_MSG * P.g.nl * ldw;
+  const long mk = TH_MSG * ((long)m * ldw + kq);
+  const double ft = P.ftnorm;
 
   double w[R], b[R];
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     int r = r0 + t;
-    bool ok = kok && r < nr && PHASE != 4;
+    bool ok = kok && r < nr && PHASE != 4 && PHASE != 5;
     w[t] = ok ? wcol[(long)r * ldw] : 0.0;
   }
   // pivots of this chunk: betc = betinv of the row before the chunk (src/ocisubs.F:472-477).
@@ -113,18 +126,31 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     }
   }
   // values entering the slab from the other ranks
-  double uin = (PHASE == 4) ? 1.0 : 0.0, vin = 0.0;
-  if (PHASE == 2 && kq < P.g.nk) {
-    double u = 0.0;
-    for (int rk = 0; rk < P.rank; ++rk) u = P.gath[rk * msg + mk] + P.gath[rk * msg + mk + 1] * u;
-    uin = u;
-    double v = 0.0;
-    for (int s = P.nranks - 1; s > P.rank; --s) {
-      double us = uin; // value entering rank s: continue the forward chain from this rank
-      for (int t = P.rank; t < s; ++t) us = P.gath[t * msg + mk] + P.gath[t * msg + mk + 1] * us;
-      v = P.gath[s * msg + mk + 2] + P.gath[s * msg + mk + 3] * us + P.gath[s * msg + mk + 1] * v;
-    }
-    vin = v;
+  double uin = (PHASE == 4) ? 1.0 : 0.0, vin = (PHASE == 5) ? 1.0 : 0.0;
+  if (PHASE == 2) {
+    // lane s stands for rank s (at most 64 slabs); wave wv works on wavenumber kq
+    const bool act = lane < P.nranks && kq < P.g.nk;
+    const double *gs = P.gath + (long)lane * msg + mk;
+    const double gCf = act ? gs[0] : 0.0, gD = act ? gs[1] : 1.0, gCb = act ? gs[2] : 0.0, gE = act ? gs[3] : 0.0;
+    const double gS0 = act ? gs[4] : 0.0, gSP = act ? gs[5] : 0.0, gSQ = act ? gs[6] : 0.0;
+    // forward chain: value leaving rank s = Cf_s + D_s * (value entering rank s), nothing enters rank 0
+    double Cs = gCf, Ds = gD;
+    affine_scan(Cs, Ds, lane);
+    double up = __shfl_up(Cs, 1);
+    const double uin_s = (lane == 0) ? 0.0 : up;
+    // backward chain, last rank first: value leaving rank s downwards = Cb_s + E_s*uin_s + D_s * (value entering from above)
+    const int rr = 63 - lane;
+    double C2 = __shfl(gCb + gE * uin_s, rr), D2 = __shfl(gD, rr);
+    affine_scan(C2, D2, lane);
+    double vp = __shfl_up(C2, 1);
+    const double vin_rr = (lane == 0) ? 0.0 : vp; // enters rank rr from above
+    const double vin_s = __shfl(vin_rr, rr);
+    double term = gS0 + uin_s * gSP + vin_s * gSQ; // column sum of rank s (0 for lanes past the last rank)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off);
+    uin = __shfl(uin_s, P.rank);
+    vin = __shfl(vin_s, P.rank);
+    if (lane == 0 && kq < P.g.nk) P.ksum[(long)m * ldw + kq] = ft * term;
   }
   // ---- forward: local affine maps (zero inflow); rows past the slab are the identity
   // rows past the end of the slab are the identity map
@@ -177,37 +203,53 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   Cs = sC[cr][wv];
   Ds = sD[cr][wv];
   affine_scan(Cs, Ds, lane);
-  if (PHASE == 1 || PHASE == 4) {
-    if (lane == 63 && kq < P.g.nk) {
-      if (PHASE == 4) {
-        P.slabDE[2 * ((long)m * ldw + kq)] = D_tot; // gain of the slab
-        P.slabDE[2 * ((long)m * ldw + kq) + 1] = Cs; // E: backward image of the unit forward response
-      } else {
-        P.send[mk] = Cf_tot;
-        P.send[mk + 1] = P.slabDE[2 * ((long)m * ldw + kq)];
-        P.send[mk + 2] = Cs;
-        P.send[mk + 3] = P.slabDE[2 * ((long)m * ldw + kq) + 1];
-      }
-    }
-    return;
-  }
+  const double Cb_tot = __shfl(Cs, 63); // first value of the zero-inflow backward sweep
   {
     double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
     sIn[cr][wv] = (lane == 0) ? vin : Cprev + Dprev * vin;
   }
   __syncthreads();
   double v = sIn[c][kk];
-  const double ft = P.ftnorm;
+  double colsum = 0.0;
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
     if (!PRED || r0 + t < nr) {
       v = w[t] - a * b[t] * v;
       w[t] = v;
+      colsum += v;
     }
   }
+  if (PHASE == 0 || PHASE == 2) {
 #pragma unroll
-  for (int t = 0; t < R; ++t) {
-    int r = r0 + t;
-    if (kok && r < nr) wcol[(long)r * ldw] = ft * w[t];
+    for (int t = 0; t < R; ++t) {
+      int r = r0 + t;
+      if (kok && r < nr) wcol[(long)r * ldw] = ft * w[t];
+    }
+  }
+  if (PHASE == 2) return; // the basin-wide column sums came from the summaries
+  // column sum of this slab: chunks in a fixed order (lanes of wave wv = chunks of wavenumber kq)
+  sC[c][kk] = colsum;
+  __syncthreads();
+  double tot = sC[lane][wv];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+  if (lane != 0 || kq >= P.g.nk) return;
+  double *cst = P.slabDE + 4 * ((long)m * ldw + kq); // D, E, SP, SQ of this slab
+  if (PHASE == 0) {
+    P.ksum[(long)m * ldw + kq] = ft * tot;
+  } else if (PHASE == 1) {
+    P.send[mk] = Cf_tot;
+    P.send[mk + 1] = cst[0];
+    P.send[mk + 2] = Cb_tot;
+    P.send[mk + 3] = cst[1];
+    P.send[mk + 4] = tot;
+    P.send[mk + 5] = cst[2];
+    P.send[mk + 6] = cst[3];
+  } else if (PHASE == 4) {
+    cst[0] = D_tot;
+    cst[1] = Cb_tot;
+    cst[2] = tot;
+  } else {
+    cst[3] = tot;
   }
 }

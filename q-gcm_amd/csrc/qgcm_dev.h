@@ -82,7 +82,8 @@ struct QgThomasParams {
   QgGeom g;
   const double *gath; // distributed sweep: all ranks' slab maps (rank-major), else nullptr
   double *send;       // distributed sweep: this rank's slab map
-  double *slabDE;     // (2, ldw, nl): gain D and E of this slab (PHASE 4 writes, PHASE 1 reads)
+  double *slabDE;     // (4, ldw, nl): D, E, SP, SQ of this slab (PHASE 4/5 write, PHASE 1 reads)
+  double *ksum;       // (ldw, nl): ftnorm * column sums of the solution per spectral index (see k_thomas.h)
   int rank, nranks;
   double *wrk;
   const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index
@@ -114,8 +115,8 @@ struct QgBdyParams {
 
 struct QgConstrParams {
   QgGeom g;
-  const double *partials; // y-slab run: all ranks' xin partials (rank-major), npart ranks
-  int npart;
+  const double *ksum; // (ldw, nl) spectral column sums of the solution (k_thomas)
+  const double *wcot; // (ldw) sum over the interior points of sin(k i pi/n): 2cot(k pi/2n)-weights of dsint's synthesis, 0 for even k
   const double *rowsum;
   const double *wrk;
   QgScalars *sc;

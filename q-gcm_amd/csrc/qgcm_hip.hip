@@ -51,7 +51,8 @@ struct qgcm_hip_ctx {
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
   double *wrk, *rowsum;
   double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
-  double *slabDE;                          // y-slab summary constants (gain D, E) per (mode, wavenumber)
+  double *slabDE;                          // y-slab summary constants (D, E, SP, SQ) per (mode, wavenumber)
+  double *ksum, *wcot;                     // spectral column sums of the solution and their cot weights (k_thomas.h)
   int *rconv, *rconv_tmp;                  // row from which the Thomas pivots are stationary
   double *bpart;                           // cyclic: partial boundary line sums (k_cyc_bsums -> k_constr_cyc)
   int thR;                                 // rows per chunk of the Thomas kernel
@@ -186,7 +187,9 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->wrk, W * g.nl)) return 1;
   if (dalloc(&c->boc, (size_t)g.ldw * g.nl) || dalloc(&c->betc, (size_t)g.ldw * TH_NC * g.nl)) return 1;
   if (dalloc(&c->boc_tmp, (size_t)g.ldw) || dalloc(&c->betc_tmp, (size_t)g.ldw * TH_NC)) return 1;
-  if (dalloc(&c->slabDE, (size_t)2 * g.ldw * g.nl)) return 1;
+  if (dalloc(&c->slabDE, (size_t)4 * g.ldw * g.nl)) return 1;
+  if (dalloc(&c->ksum, (size_t)g.ldw * g.nl)) return 1;
+  if (dalloc(&c->wcot, (size_t)g.ldw)) return 1;
   if (dalloc(&c->bpart, (size_t)5 * BSUM_NB * 2 * g.nl)) return 1;
   HIPCHECK(hipMalloc((void **)&c->rconv, sizeof(int) * g.ldw * g.nl));
   HIPCHECK(hipMalloc((void **)&c->rconv_tmp, sizeof(int) * g.ldw));
@@ -220,13 +223,13 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   if (c->sc_comm) {
     QgSlabComm *m = c->sc_comm;
     if (m->comm) m->api->CommDestroy(m->comm);
-    double *cb[] = {m->th_send, m->th_gath, m->x_send, m->x_gath, m->h_send, m->h_gath};
+    double *cb[] = {m->th_send, m->th_gath, m->h_send, m->h_gath};
     for (double *p : cb)
       if (p) hipFree(p);
     delete m;
   }
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
-                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
+                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->ksum, c->wcot, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
@@ -334,9 +337,20 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   c->grid_set = true;
-  // slab summary constants (gain and backward image of the unit response), once
+  // slab summary constants (gain, backward image and column sums of the unit responses), once
   if (launch_thomas(c, c->wrk, c->boc, c->betc, g.nl, 4, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
-  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (launch_thomas(c, c->wrk, c->boc, c->betc, g.nl, 5, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  {
+    // weights of the spectral area integral (k_thomas.h): sum_{i=1}^{n-1} 2 sin(k i pi/n) = 2 cot(k pi/2n), k odd
+    std::vector<double> wc((size_t)g.ldw, 0.0);
+    if (!g.cyc)
+      for (int k = 1; k <= g.nk; k += 2) {
+        const double h = (double)k * (pi / (2.0 * (double)N));
+        wc[k - 1] = 2.0 * cos(h) / sin(h);
+      }
+    HIPCHECK(hipMemcpyAsync(c->wcot, wc.data(), wc.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+  }
   return 0;
 }
 
@@ -629,7 +643,7 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   P.wrk = wrk;
   P.twid = c->twid;
   P.sintab = c->sintab;
-  P.rowsum = inverse ? c->rowsum : nullptr;
+  P.rowsum = (inverse && g.cyc) ? c->rowsum : nullptr; // box: area integrals come from k_thomas (ksum)
   P.N = c->fftN;
   P.nfac = c->nfac;
   for (int f = 0; f < c->nfac; ++f) P.fac[f] = c->fac[f];
@@ -648,13 +662,10 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   }
   // wave-per-row-pair fast path when nxto = 64*M with an in-register M-point DFT available
   if (c->fftN == 64 * 15 && !c->force_generic_dst) {
-    if (inverse) hipLaunchKernelGGL((k_dst64<15, true>), grid64, dim3(D64_NT), 0, st, P);
-    else hipLaunchKernelGGL((k_dst64<15, false>), grid64, dim3(D64_NT), 0, st, P);
+    hipLaunchKernelGGL((k_dst64<15, false>), grid64, dim3(D64_NT), 0, st, P);
   } else if (c->fftN == 64 * 3 && !c->force_generic_dst) {
-    if (inverse) hipLaunchKernelGGL((k_dst64<3, true>), grid64, dim3(D64_NT), 0, st, P);
-    else hipLaunchKernelGGL((k_dst64<3, false>), grid64, dim3(D64_NT), 0, st, P);
-  } else if (inverse) hipLaunchKernelGGL((k_dst_box<true>), grid, dim3(DST_NT), c->dst_lds, st, P);
-  else hipLaunchKernelGGL((k_dst_box<false>), grid, dim3(DST_NT), c->dst_lds, st, P);
+    hipLaunchKernelGGL((k_dst64<3, false>), grid64, dim3(D64_NT), 0, st, P);
+  } else hipLaunchKernelGGL((k_dst_box<false>), grid, dim3(DST_NT), c->dst_lds, st, P);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -668,6 +679,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
   P.g = g;
   P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
   P.slabDE = c->slabDE;
+  P.ksum = c->ksum;
   P.wrk = wrk;
   P.boc = boc;
   P.betc = betc;
@@ -683,7 +695,8 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
     case 0: hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, st, P); break;        \
     case 1: hipLaunchKernelGGL((k_thomas<RV, 1>), grid, dim3(TH_NT), 0, st, P); break;        \
     case 2: hipLaunchKernelGGL((k_thomas<RV, 2>), grid, dim3(TH_NT), 0, st, P); break;        \
-    default: hipLaunchKernelGGL((k_thomas<RV, 4>), grid, dim3(TH_NT), 0, st, P); break;       \
+    case 4: hipLaunchKernelGGL((k_thomas<RV, 4>), grid, dim3(TH_NT), 0, st, P); break;        \
+    default: hipLaunchKernelGGL((k_thomas<RV, 5>), grid, dim3(TH_NT), 0, st, P); break;       \
   }
   switch (c->thR) {
     case 1: QG_TH(1); break;
@@ -701,7 +714,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
 
 static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P);
 
-static int launch_constr(qgcm_hip_ctx *c, const double *partials = nullptr, int npart = 0) {
+static int launch_constr(qgcm_hip_ctx *c) {
   const QgGeom &g = c->g;
   QgConstrParams P;
   fill_constr_params(c, P);
@@ -730,8 +743,6 @@ static int launch_constr(qgcm_hip_ctx *c, const double *partials = nullptr, int 
     HIPCHECK(hipGetLastError());
     return 0;
   }
-  P.partials = partials;
-  P.npart = npart;
   KTimer t(c, KN_CONSTR);
   switch (g.nl) {
     case 2: hipLaunchKernelGGL((k_constr_box<2>), dim3(1), dim3(64), 0, c->stream, P); break;
@@ -749,6 +760,8 @@ static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P) {
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.rowsum = c->rowsum;
+  P.ksum = c->ksum;
+  P.wcot = c->wcot;
   P.wrk = c->wrk;
   P.sc = c->sc;
   P.cs = c->cs;
@@ -869,9 +882,10 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
   } else {
     if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
     if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+    if (!c->g.cyc && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
     if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
   }
-  if (launch_constr(c)) return 1;
+  if (c->g.cyc && launch_constr(c)) return 1; // cyclic: line and area sums of the transformed rows
   if (launch_unpack(c, fuse_bdy)) return 1;
   c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
   return 0;
@@ -1008,7 +1022,7 @@ extern "C" int qgcm_hip_row_transform(qgcm_hip_handle c, int inverse) {
   return launch_dst(c, c->wrk, c->g.nl, inverse != 0);
 }
 
-extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? 4 * c->g.nl * c->g.ldw : 0; }
+extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? TH_MSG * c->g.nl * c->g.ldw : 0; }
 
 extern "C" int qgcm_hip_thomas_phase(qgcm_hip_handle c, int phase, const double *gath_dev, double *send_dev, int rank,
                                      int nranks) {
@@ -1019,24 +1033,10 @@ extern "C" int qgcm_hip_thomas_phase(qgcm_hip_handle c, int phase, const double 
   return launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, phase, gath_dev, send_dev, rank, nranks, 0, nullptr);
 }
 
-extern "C" int qgcm_hip_xin_partial(qgcm_hip_handle c, double *send_dev) {
-  if (check_ready(c, "qgcm_hip_xin_partial")) return 1;
-  QgConstrParams P;
-  fill_constr_params(c, P);
-  switch (c->g.nl) {
-    case 2: hipLaunchKernelGGL((k_xin_partial<2>), dim3(1), dim3(64), 0, c->stream, P, send_dev); break;
-    case 3: hipLaunchKernelGGL((k_xin_partial<3>), dim3(1), dim3(64), 0, c->stream, P, send_dev); break;
-    case 4: hipLaunchKernelGGL((k_xin_partial<4>), dim3(1), dim3(64), 0, c->stream, P, send_dev); break;
-    default: QG_FAIL("k_xin_partial: unsupported nlo");
-  }
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
-extern "C" int qgcm_hip_constr_partials(qgcm_hip_handle c, const double *gath_dev, int nranks) {
-  if (check_ready(c, "qgcm_hip_constr_partials")) return 1;
-  if (!c->homog_set) QG_FAIL("qgcm_hip_constr_partials: homogeneous solutions not set");
-  return launch_constr(c, gath_dev, nranks);
+extern "C" int qgcm_hip_constr(qgcm_hip_handle c) {
+  if (check_ready(c, "qgcm_hip_constr")) return 1;
+  if (!c->homog_set) QG_FAIL("qgcm_hip_constr: homogeneous solutions not set");
+  return launch_constr(c);
 }
 
 extern "C" int qgcm_hip_unpack(qgcm_hip_handle c, int fuse_ocqbdy) {
@@ -1078,18 +1078,16 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
       return qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks);
     case 2:
       if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
+      if (qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
       if (qgcm_hip_row_transform(c, 1)) return 1;
-      return qgcm_hip_xin_partial(c, b);
-    case 3:
-      if (qgcm_hip_constr_partials(c, a, nranks)) return 1;
       if (qgcm_hip_unpack(c, 1)) return 1;
       if (nranks > 1) return qgcm_hip_halo_pack(c, b, cc);
       return 0;
-    case 4:
+    case 3:
       if (nranks > 1 && qgcm_hip_halo_unpack(c, a, b)) return 1;
       if (flags & 1) return qgcm_hip_lf_average(c);
       return 0;
-    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..4");
+    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..3");
   }
 }
 
@@ -1131,14 +1129,13 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   m->nranks = nranks;
   const char *hp = getenv("QGCM_HIP_HALO_P2P");
   m->halo_p2p = hp && atoi(hp) != 0;
-  m->th_len = (size_t)4 * g.nl * g.ldw;
+  m->th_len = (size_t)TH_MSG * g.nl * g.ldw;
   m->halo_len = (size_t)4 * g.nl * g.ldx;
   c->sc_comm = m; // owned by the handle from here on (freed in qgcm_hip_destroy)
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   NCCLCHECK(api, api->CommInitRank(&m->comm, nranks, u, rank));
   struct { double **p; size_t n; } bufs[] = {{&m->th_send, m->th_len}, {&m->th_gath, m->th_len * nranks},
-                                             {&m->x_send, (size_t)QG_MAXL}, {&m->x_gath, (size_t)QG_MAXL * nranks},
                                              {&m->h_send, 2 * m->halo_len}, {&m->h_gath, 2 * m->halo_len * nranks}};
   for (auto &b : bufs) {
     HIPCHECK(hipMalloc((void **)b.p, b.n * sizeof(double)));
@@ -1150,22 +1147,19 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   return 0;
 }
 
-// one distributed ocean step: four communication-free stages (the same calls SlabOcean.step makes through
-// qgcm_hip_slab_stage) and three exchanges, all ordered on c->stream; no host synchronisation
+// one distributed ocean step: three communication-free stages (the same calls SlabOcean.step makes through
+// qgcm_hip_slab_stage) and two exchanges, all ordered on c->stream; no host synchronisation
 static int slab_step(qgcm_hip_ctx *c, int s) {
   QgSlabComm *m = c->sc_comm;
   const int r = m->rank, P = m->nranks;
-  const int nl = c->g.nl;
   const size_t n = m->halo_len;
   // 1. tendency, forward row transform, slab summary of the two y sweeps
   if (qgcm_hip_slab_stage(c, 1, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
   NCCLCHECK(m->api, m->api->AllGather(m->th_send, m->th_gath, m->th_len, ncclDouble, m->comm, c->stream));
-  // 2. both sweeps from the composed inflows, inverse row transform, area-integral partials
-  if (qgcm_hip_slab_stage(c, 2, m->th_gath, m->x_send, nullptr, r, P, 0)) return 1;
-  NCCLCHECK(m->api, m->api->AllGather(m->x_send, m->x_gath, (size_t)nl, ncclDouble, m->comm, c->stream));
-  // 3. constraints (partials added in rank order on every rank), modes -> layers + boundary PV, edge rows out
+  // 2. both sweeps from the composed inflows (+ basin-wide area integrals), constraints, inverse row transform,
+  //    modes -> layers + boundary PV, edge rows out
   double *to_lo = r > 0 ? m->h_send : nullptr, *to_hi = r < P - 1 ? m->h_send + n : nullptr;
-  if (qgcm_hip_slab_stage(c, 3, m->x_gath, to_lo, to_hi, r, P, 0)) return 1;
+  if (qgcm_hip_slab_stage(c, 2, m->th_gath, to_lo, to_hi, r, P, 0)) return 1;
   const double *from_lo = nullptr, *from_hi = nullptr;
   if (P > 1) {
     if (m->halo_p2p) {
@@ -1187,10 +1181,10 @@ static int slab_step(qgcm_hip_ctx *c, int s) {
     if (r > 0) from_lo = m->h_gath + (size_t)(2 * (r - 1) + 1) * n;  // what the lower neighbour sent upwards
     if (r < P - 1) from_hi = m->h_gath + (size_t)(2 * (r + 1)) * n;  // what the upper neighbour sent downwards
   }
-  // 4. edge rows in, leapfrog averaging after steps s with (s-1) mod 25 == 0
+  // 3. edge rows in, leapfrog averaging after steps s with (s-1) mod 25 == 0
   const int avg = (s - 1) % 25 == 0 ? 1 : 0;
   if (P > 1 || avg)
-    if (qgcm_hip_slab_stage(c, 4, (double *)from_lo, (double *)from_hi, nullptr, r, P, avg)) return 1;
+    if (qgcm_hip_slab_stage(c, 3, (double *)from_lo, (double *)from_hi, nullptr, r, P, avg)) return 1;
   return 0;
 }
 

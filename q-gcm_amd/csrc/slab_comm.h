@@ -60,7 +60,6 @@ struct QgSlabComm {
   int rank = 0, nranks = 1;
   bool halo_p2p = false;
   size_t th_len = 0, halo_len = 0;
-  double *th_send = nullptr, *th_gath = nullptr; // Thomas slab summaries (Cf, D, Cb, E)
-  double *x_send = nullptr, *x_gath = nullptr;   // area-integral partials
+  double *th_send = nullptr, *th_gath = nullptr; // slab summaries of the y sweeps (k_thomas.h, TH_MSG per mode and wavenumber)
   double *h_send = nullptr, *h_gath = nullptr;   // edge rows: [to lower | to upper] per rank
 };

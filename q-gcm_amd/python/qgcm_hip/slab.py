@@ -250,11 +250,8 @@ class HipSlab:
         check(self.L.qgcm_hip_thomas_phase(self.h, int(phase), self._ptr(gath), self._ptr(send), self.rank, self.nranks))
         self._done()
 
-    def xin_partial(self, send):
-        check(self.L.qgcm_hip_xin_partial(self.h, self._ptr(send))); self._done()
-
-    def constr_partials(self, gath):
-        check(self.L.qgcm_hip_constr_partials(self.h, self._ptr(gath), self.nranks)); self._done()
+    def constr(self):
+        check(self.L.qgcm_hip_constr(self.h)); self._done()
 
     def unpack(self, fuse_ocqbdy=True):
         check(self.L.qgcm_hip_unpack(self.h, int(fuse_ocqbdy))); self._done()
@@ -298,8 +295,6 @@ class SlabOcean:
         self.stream_ctx = stream_ctx  # context manager factory that makes torch's current stream the slab's stream
         self.th_send = [s.new_buffer(s.th_len) for s in slabs]
         self.th_gath = [s.new_buffer(s.th_len * self.P) for s in slabs]
-        self.x_send = [s.new_buffer(nl) for s in slabs]
-        self.x_gath = [s.new_buffer(nl * self.P) for s in slabs]
         self.h_to_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
         self.h_to_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
         self.h_from_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
@@ -318,17 +313,16 @@ class SlabOcean:
         for i, x in enumerate(S):  # tendency, forward row transform, slab summary of the y sweeps
             x.stage(1, self.th_send[i])
         self._comm(cm.all_gather, self.th_gath, self.th_send)
-        for i, x in enumerate(S):  # both sweeps, inverse row transform, area-integral partials
-            x.stage(2, self.th_gath[i], self.x_send[i])
-        self._comm(cm.all_gather, self.x_gath, self.x_send)
-        for i, x in enumerate(S):  # constraints, modes -> layers (+ boundary PV), halo rows out
-            x.stage(3, self.x_gath[i], self.h_to_lo[i], self.h_to_hi[i])
+        # both sweeps + basin-wide area integrals, constraints, inverse row transform,
+        # modes -> layers (+ boundary PV), halo rows out
+        for i, x in enumerate(S):
+            x.stage(2, self.th_gath[i], self.h_to_lo[i], self.h_to_hi[i])
         if self.P > 1:
             self._comm(cm.halo_exchange, self.h_to_lo, self.h_to_hi, self.h_from_lo, self.h_from_hi)
         avg = 1 if (s - 1) % 25 == 0 else 0
         if self.P > 1 or avg:
             for i, x in enumerate(S):  # halo rows in, leapfrog averaging every 25th step
-                x.stage(4, self.h_from_lo[i], self.h_from_hi[i], None, avg)
+                x.stage(3, self.h_from_lo[i], self.h_from_hi[i], None, avg)
 
     def use_library_exchanges(self, comm_id):
         """From now on steps() runs qgcm_hip_slab_steps: the library issues the RCCL exchanges

@@ -29,11 +29,15 @@ class NumpySlab:
         self.xon = np.zeros(nl - 1)
         self.scal = np.zeros(2 * (nl - 1) + 4 * nl)
         self.wrk = np.zeros((self.nk, self.nyl, nl))
-        self.rowsum = np.zeros((self.nyl, nl))
         # owned rows that are interior to the global domain (0-based local indices)
         self.r0 = self.jlo - 1 + (1 if g0 == 1 else 0)
         self.r1 = self.jhi - 1 - (1 if g1 == self.nyg else 0)
-        self.th_len = 4 * nl * self.nk
+        self.th_len = 7 * nl * self.nk
+        # weights of the spectral area integral: sum_i 2 sin(k i pi/n) = 2 cot(k pi/2n) for odd k (k_thomas.h)
+        n = nx - 1
+        kk = np.arange(1, self.nk + 1)
+        self.wcot = np.where(kk % 2 == 1, 2.0 / np.tan(kk * np.pi / (2.0 * n)), 0.0)
+        self.ksum = np.zeros((self.nk, nl))
         self.halo_len = 4 * nl * nx
         # Thomas pivots of the slab rows (src/ocisubs.F:472-477), global recurrence
         rg0 = (self.r0 + 1 + self.joff) - 2
@@ -150,9 +154,6 @@ class NumpySlab:
     def row_transform(self, inverse):
         r0, r1 = self.r0, self.r1
         self.wrk[:, r0:r1 + 1, :] = scipy.fft.dst(self.wrk[:, r0:r1 + 1, :], type=1, axis=0)
-        if inverse:
-            self.rowsum[:] = 0.0
-            self.rowsum[r0:r1 + 1, :] = self.wrk[:, r0:r1 + 1, :].sum(axis=0)
 
     def _fwd(self, w, uin):
         """forward sweep over the slab rows from inflow uin (nk, nl)."""
@@ -174,45 +175,46 @@ class NumpySlab:
         return v
 
     def thomas_phase(self, phase, gath, send):
-        """Same single-exchange protocol as k_thomas.h: a slab is summarised by
-        (Cf, D, Cb, E) per wavenumber and mode."""
+        """Same single-exchange protocol as k_thomas.h: a slab is summarised per wavenumber
+        and mode by (Cf, D, Cb, E, S0, SP, SQ); phase 2 also leaves the basin-wide spectral
+        column sums (ksum) behind, from which constr() takes the area integrals."""
         a = self.c["aoc"]
         nl, nk = self.cfg.nlo, self.nk
-        z = np.zeros((nk, nl))
+        z, one = np.zeros((nk, nl)), np.ones((nk, nl))
         w = self.wrk[:, self.r0:self.r1 + 1, :]
+        ft = 0.5 / (self.cfg.nxpo - 1)
         if phase == 1:
             u0 = self._fwd(w, z)
             v0 = self._bwd(u0, z)
-            unit = self._fwd(np.zeros_like(w), np.ones((nk, nl)))   # forward response to unit inflow
-            E = self._bwd(unit, z)[:, 0, :]
+            bp = self._bwd(self._fwd(np.zeros_like(w), one), z)   # backward image of the unit forward response
+            q = self._bwd(np.zeros_like(w), one)                   # unit backward response
             D = np.prod(-a * self.bet, axis=1)
-            t = send.numpy().reshape(nl, nk, 4)
-            t[:, :, 0], t[:, :, 1], t[:, :, 2], t[:, :, 3] = u0[:, -1, :].T, D.T, v0[:, 0, :].T, E.T
+            t = send.numpy().reshape(nl, nk, 7)
+            for i, x in enumerate((u0[:, -1, :], D, v0[:, 0, :], bp[:, 0, :], v0.sum(axis=1), bp.sum(axis=1), q.sum(axis=1))):
+                t[:, :, i] = x.T
             return
-        g = gath.numpy().reshape(self.nranks, nl, nk, 4).transpose(0, 2, 1, 3)  # (P, nk, nl, 4)
+        g = gath.numpy().reshape(self.nranks, nl, nk, 7).transpose(0, 2, 1, 3)  # (P, nk, nl, 7)
         us = []
         u = z
         for r in range(self.nranks):
             us.append(u)
             u = g[r, :, :, 0] + g[r, :, :, 1] * u
+        vs = [None] * self.nranks
         v = z
-        for r in range(self.nranks - 1, self.rank, -1):
+        for r in range(self.nranks - 1, -1, -1):
+            vs[r] = v
             v = g[r, :, :, 2] + g[r, :, :, 3] * us[r] + g[r, :, :, 1] * v
+        tot = z
+        for r in range(self.nranks):
+            tot = tot + (g[r, :, :, 4] + us[r] * g[r, :, :, 5] + vs[r] * g[r, :, :, 6])
+        self.ksum = ft * tot
         uf = self._fwd(w, us[self.rank])
-        ft = 0.5 / (self.cfg.nxpo - 1)
-        self.wrk[:, self.r0:self.r1 + 1, :] = ft * self._bwd(uf, v)
+        self.wrk[:, self.r0:self.r1 + 1, :] = ft * self._bwd(uf, vs[self.rank])
 
-    def xin_partial(self, send):
-        send.numpy()[:] = self.rowsum.sum(axis=0)
-
-    def constr_partials(self, gath):
+    def constr(self):
         cfg, c = self.cfg, self.c
         nl = cfg.nlo
-        tot = np.zeros(nl)
-        g = gath.numpy().reshape(self.nranks, nl)
-        for r in range(self.nranks):
-            tot = tot + g[r]
-        xin = tot * cfg.dxo * cfg.dyo
+        xin = (self.wcot[:, None] * self.ksum).sum(axis=0) * cfg.dxo * cfg.dyo
         dpioc, dpiocp = self.scal[:nl - 1].copy(), self.scal[nl - 1:2 * (nl - 1)].copy()
         aient = np.zeros(nl - 1)
         aient[0] = self.xon[0]
@@ -296,9 +298,7 @@ class NumpySlab:
         if n == 1:
             self.qgostep(); self.row_transform(0); self.thomas_phase(1, None, a)
         elif n == 2:
-            self.thomas_phase(2, a, None); self.row_transform(1); self.xin_partial(b)
-        elif n == 3:
-            self.constr_partials(a); self.unpack(True)
+            self.thomas_phase(2, a, None); self.constr(); self.row_transform(1); self.unpack(True)
             if self.nranks > 1:
                 self.halo_pack(b, c)
         else:
