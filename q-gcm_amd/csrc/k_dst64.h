@@ -130,23 +130,13 @@ __device__ __forceinline__ void dftM<15>(cplx *a) {
   for (int k = 0; k < 15; ++k) a[k] = t[k];
 }
 
-// grid: (ceil(npairs / 4), nlayers), block 256 = 4 independent waves
-template <int M, bool ROWSUM>
-__global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
+// The transform of one row pair by one wave: reads rowa/rowb (global), leaves the two output rows
+// in the wave's LDS buffer F viewed as doubles: row a at raw[pidx(i)], row b at raw[NP + pidx(i)],
+// i = 0..N-2, pidx(i) = i + (i >> 4), NP = N + N/16.  rsa / rsb = sums of the output rows.
+template <int M>
+__device__ __forceinline__ void dst64_core(const QgDstParams &P, const double *rowa, const double *rowb, bool has_b,
+                                           cplx *F, cplx *W64, int lane, double &rsa, double &rsb) {
   constexpr int N = 64 * M, n = N - 1, NS2 = n / 2; // n odd: NS2 = N/2 - 1 = K
-  __shared__ __align__(16) cplx Fsh[D64_WAVES][M * D64_ROW];
-  __shared__ __align__(16) cplx W64sh[D64_WAVES][64]; // exp(-2 pi i t / 64), per wave copy
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int ny = P.g.ny, ldw = P.g.ldw;
-  const int m = blockIdx.y + P.layer0;
-  const int pair = blockIdx.x * D64_WAVES + wv;
-  const int ja = P.g.jr0 + 2 * pair;
-  if (ja > P.g.jr1) return; // whole wave leaves; no workgroup barrier is ever used
-  const bool has_b = (ja + 1 <= P.g.jr1);
-  double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
-  double *rowb = rowa + ldw;
-  cplx *F = Fsh[wv];
   double *raw = reinterpret_cast<double *>(F); // rows a, b: raw[0..N-1], raw[N..2N-1]
 
   // Everything this lane will need from global tables is requested up front so
@@ -165,7 +155,6 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
     const int j = 64 * n1 + lane;
     snv[n1] = P.sintab[(j <= NS2) ? j : N - j];
   }
-  cplx *W64 = W64sh[wv];
   {
     double2 w = P.twid[M * lane];
     W64[lane] = {w.x, w.y};
@@ -302,7 +291,8 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   // the per-lane runs of 16 consecutive outputs fall on distinct LDS banks.
   constexpr int NP = N + N / 16; // padded row length
   auto pidx = [](int i) { return i + (i >> 4); };
-  double rsa = 0.0, rsb = 0.0;
+  rsa = 0.0;
+  rsb = 0.0;
   if (lane == 0) {
     raw[0] = b1a;
     raw[NP] = b1b;
@@ -326,6 +316,28 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
     }
   }
   wave_lds_sync();
+}
+
+// grid: (ceil(npairs / 4), nlayers), block 256 = 4 independent waves
+template <int M, bool ROWSUM>
+__global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
+  constexpr int N = 64 * M;
+  __shared__ __align__(16) cplx Fsh[D64_WAVES][M * D64_ROW];
+  __shared__ __align__(16) cplx W64sh[D64_WAVES][64]; // exp(-2 pi i t / 64), per wave copy
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int ny = P.g.ny, ldw = P.g.ldw;
+  const int m = blockIdx.y + P.layer0;
+  const int pair = blockIdx.x * D64_WAVES + wv;
+  const int ja = P.g.jr0 + 2 * pair;
+  if (ja > P.g.jr1) return; // whole wave leaves; no workgroup barrier is ever used
+  const bool has_b = (ja + 1 <= P.g.jr1);
+  double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
+  double *rowb = rowa + ldw;
+  double rsa, rsb;
+  dst64_core<M>(P, rowa, rowb, has_b, Fsh[wv], W64sh[wv], lane, rsa, rsb);
+  const double *raw = reinterpret_cast<const double *>(Fsh[wv]);
+  constexpr int NP = N + N / 16;
   {
     double2 *ga = reinterpret_cast<double2 *>(rowa);
     double2 *gb = reinterpret_cast<double2 *>(rowb);
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
     for (int u = 0; u < (N / 2 + 63) / 64; ++u) {
       int t = lane + 64 * u;
       if (t < N / 2) {
-        const int i = pidx(2 * t); // 2t and 2t+1 share a 16-group: consecutive after padding
+        const int i = 2 * t + ((2 * t) >> 4); // 2t and 2t+1 share a 16-group: consecutive after padding
         ga[t] = double2{raw[i], raw[i + 1]};
         if (has_b) gb[t] = double2{raw[NP + i], raw[NP + i + 1]};
       }
@@ -354,3 +366,153 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
 
 // back to the library default (-ffp-contract=off) for everything included after this file
 #pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------
+// Inverse row transform FUSED with the modes -> layers step (and, with BDY, the boundary PV):
+// K3 (inverse) + K7 (+ K8) in one launch.  A workgroup = NL waves = the NL modes of one row pair;
+// each wave transforms its mode into LDS as above, then all waves combine the modes point by
+// point exactly as k_unpack_box does (same expressions, same order; contraction off), writing the
+// new po - the transformed field never goes to HBM (saves 2 passes over wrk and a launch).
+// The workgroups of the first / last interior row also write the wall rows (G = 1, nyg).
+// Reference: src/ocisubs.F:494-499 (inverse dsint), 377-401 (unpack), src/vorsubs.F:245-388.
+// grid: (npairs), block 64*NL.
+// ---------------------------------------------------------------------------
+template <int M, int NL, bool BDY>
+__global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, const QgUnpackParams U, const QgBdyParams B) {
+  constexpr int N = 64 * M, NP = N + N / 16;
+  __shared__ __align__(16) cplx Fsh[NL][M * D64_ROW];
+  __shared__ __align__(16) cplx W64sh[NL][64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6; // = mode
+  const int ldw = P.g.ldw;
+  const int ja = P.g.jr0 + 2 * blockIdx.x;     // local rows ja, ja+1 (grid is exactly the pairs)
+  const bool has_b = (ja + 1 <= P.g.jr1);
+  const long fs = U.g.fstride;
+  // Work split of the combine step: the nx-2 interior columns go round-robin over the threads (NIT
+  // full sweeps, nx = N+1); the two wall columns are done by lane 0 of waves 0 (W) and 1 (E).
+  // Everything the combine step reads from global memory is requested BEFORE the transform.
+  constexpr int NX = N + 1, NT = 64 * NL, NIT = (NX - 2 + NT - 1) / NT;
+  double oc[2][NIT][NL - 1];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int gi = 2 + tid + it * NT;
+      const bool ok = gi <= NX - 1 && (r == 0 || has_b);
+      const long o = (long)(ja + r - 1) * U.g.ldx + (gi - 1);
+#pragma unroll
+      for (int m = 1; m < NL; ++m) oc[r][it][m - 1] = ok ? U.ochom[fs * (m - 1) + o] : 0.0;
+    }
+  const bool wallcol = (lane == 0 && wv < 2);
+  const int gw = (wv == 0) ? 1 : NX, gn = (wv == 0) ? 2 : NX - 1; // wall column and its inward neighbour
+  double ocw[2][NL - 1], ocn[2][NL - 1], byw[2], ddw[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const bool ok = wallcol && (r == 0 || has_b);
+    const long ow = (long)(ja + r - 1) * U.g.ldx + (gw - 1), on = (long)(ja + r - 1) * U.g.ldx + (gn - 1);
+#pragma unroll
+    for (int m = 1; m < NL; ++m) {
+      ocw[r][m - 1] = ok ? U.ochom[fs * (m - 1) + ow] : 0.0;
+      ocn[r][m - 1] = ok ? U.ochom[fs * (m - 1) + on] : 0.0;
+    }
+    byw[r] = (BDY && ok) ? B.beta * B.yporel[ja + r - 1] : 0.0;
+    ddw[r] = (BDY && ok) ? B.ddynoc[ow] : 0.0;
+  }
+  double hc[NL];
+#pragma unroll
+  for (int m = 1; m < NL; ++m) hc[m] = U.sc->hclco[m - 1];
+  {
+    const double *rowa = P.wrk + P.g.wstride * wv + (long)(ja - 1) * ldw;
+    double rsa, rsb;
+    dst64_core<M>(P, rowa, rowa + ldw, has_b, Fsh[wv], W64sh[wv], lane, rsa, rsb);
+  }
+  __syncthreads();
+  const int nx = U.g.nx, nyg = U.g.nyg, joff = U.g.joff;
+  // unpack_point of k_misc.h with the transformed rows taken from LDS; sel: 0 row a, 1 row b, -1 wall row;
+  // ocv: prefetched ochom values of the point, or nullptr (read them here)
+  auto point = [&](int gi, int gj, int sel, const double *ocv, double *pl) {
+    const long o = (long)(gj - 1) * U.g.ldx + (gi - 1);
+    const bool inner = (sel >= 0 && gi >= 2 && gi <= nx - 1);
+    const int ip = (gi - 2) + ((gi - 2) >> 4) + (sel > 0 ? NP : 0);
+    double pm[NL];
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+      const double wvv = inner ? reinterpret_cast<const double *>(Fsh[m])[ip] : 0.0;
+      pm[m] = (m == 0) ? wvv : wvv + hc[m] * (ocv ? ocv[m - 1] : U.ochom[fs * (m - 1) + o]);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < NL; ++m) v = v + U.ctm2l[m + NL * k] * pm[m];
+      pl[k] = v;
+    }
+  };
+  // boundary PV of one wall point (k_unpack_box / k_ocqbdy): by = beta*yporel(j), dd = ddynoc(i,j)
+  auto bdy_q = [&](long o, const double *pl, const double *pin, double by, double dd) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      double ap;
+      if (k == 0) ap = B.f0A[0] * pl[0] + B.f0A[NL] * pl[1];
+      else if (k == NL - 1) ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k];
+      else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
+      double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
+      if (k == NL - 1) q = q + dd;
+      B.qo[fs * k + o] = q;
+    }
+  };
+  // wall columns (W by wave 0, E by wave 1)
+  if (wallcol) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r == 1 && !has_b) break;
+      const int gj = ja + r;
+      const long o = (long)(gj - 1) * U.g.ldx + (gw - 1);
+      double pl[NL];
+      point(gw, gj, r, ocw[r], pl);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
+      if (BDY) {
+        double pin[NL];
+        point(gn, gj, r, ocn[r], pin);
+        bdy_q(o, pl, pin, byw[r], ddw[r]);
+      }
+    }
+  }
+  // interior columns
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && !has_b) break;
+    const int gj = ja + r;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int gi = 2 + tid + it * NT;
+      if (gi > nx - 1) break;
+      const long o = (long)(gj - 1) * U.g.ldx + (gi - 1);
+      double pl[NL];
+      point(gi, gj, r, oc[r][it], pl);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
+    }
+  }
+  // wall rows of the basin (G = 1, nyg): done by the workgroup of the first / last interior row
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && !has_b) break;
+    const int gj = ja + r, G = gj + joff;
+    const int wall = (G == 2) ? gj - 1 : (G == nyg - 1 ? gj + 1 : 0);
+    if (!wall) continue;
+    for (int gi = tid + 1; gi <= nx; gi += NT) {
+      const long ow = (long)(wall - 1) * U.g.ldx + (gi - 1);
+      double pw[NL], pl[NL];
+      point(gi, wall, -1, nullptr, pw);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) U.pnew[fs * k + ow] = pw[k];
+      if (BDY) {
+        point(gi, gj, r, nullptr, pl);
+        bdy_q(ow, pw, pl, B.beta * B.yporel[wall - 1], B.ddynoc[ow]);
+      }
+    }
+  }
+}

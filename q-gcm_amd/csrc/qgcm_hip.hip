@@ -65,6 +65,7 @@ struct qgcm_hip_ctx {
   bool grid_set, homog_set;
   bool whole; // the handle owns the whole domain (no y-slab neighbours)
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
+  bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
   hipError_t timer_err = hipSuccess;
@@ -205,6 +206,8 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   {
     const char *e = getenv("QGCM_HIP_GENERIC_DST");
     c->force_generic_dst = e && e[0] == '1';
+    const char *f = getenv("QGCM_HIP_NO_FUSED_UNPACK");
+    c->no_fused_unpack = f && f[0] == '1';
   }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
@@ -809,6 +812,55 @@ static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
   return 0;
 }
 
+// box fast path: inverse row transform + modes -> layers (+ boundary PV) in one launch (k_dst64_unpack)
+static bool can_fuse_dst_unpack(const qgcm_hip_ctx *c) {
+  return !c->g.cyc && !c->force_generic_dst && !c->no_fused_unpack && (c->fftN == 64 * 15 || c->fftN == 64 * 3) &&
+         c->g.nl >= 2 && c->g.nl <= 4;
+}
+
+static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
+  const QgGeom &g = c->g;
+  QgDstParams D;
+  memset(&D, 0, sizeof(D));
+  D.g = g;
+  D.wrk = c->wrk;
+  D.twid = c->twid;
+  D.sintab = c->sintab;
+  D.N = c->fftN;
+  D.nlayers = g.nl;
+  QgUnpackParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.wrk = c->wrk;
+  P.ochom = c->ochom;
+  P.pnew = c->p[c->ip ^ 1];
+  P.sc = c->sc;
+  for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  QgBdyParams B;
+  fill_bdy_params(c, B);
+  const int nrows = g.jr1 - g.jr0 + 1;
+  dim3 grid((nrows + 1) / 2);
+  KTimer t(c, KN_DSTI);
+#define QG_DU(MV, NLV)                                                                                          \
+  if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true>), grid, dim3(64 * NLV), 0, c->stream, D, P, B); \
+  else hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B)
+#define QG_DU_NL(MV)                 \
+  switch (g.nl) {                    \
+    case 2: QG_DU(MV, 2); break;     \
+    case 3: QG_DU(MV, 3); break;     \
+    default: QG_DU(MV, 4); break;    \
+  }
+  if (c->fftN == 64 * 15) {
+    QG_DU_NL(15)
+  } else {
+    QG_DU_NL(3)
+  }
+#undef QG_DU_NL
+#undef QG_DU
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
 static void fill_bdy_params(qgcm_hip_ctx *c, QgBdyParams &P) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
@@ -883,6 +935,11 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
     if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
     if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
     if (!c->g.cyc && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
+    if (can_fuse_dst_unpack(c)) {
+      if (launch_dst_unpack(c, fuse_bdy)) return 1;
+      c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
+      return 0;
+    }
     if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
   }
   if (c->g.cyc && launch_constr(c)) return 1; // cyclic: line and area sums of the transformed rows
@@ -1079,8 +1136,13 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
     case 2:
       if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
       if (qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
-      if (qgcm_hip_row_transform(c, 1)) return 1;
-      if (qgcm_hip_unpack(c, 1)) return 1;
+      if (can_fuse_dst_unpack(c)) {
+        if (launch_dst_unpack(c, true)) return 1;
+        c->ip ^= 1;
+      } else {
+        if (qgcm_hip_row_transform(c, 1)) return 1;
+        if (qgcm_hip_unpack(c, 1)) return 1;
+      }
       if (nranks > 1) return qgcm_hip_halo_pack(c, b, cc);
       return 0;
     case 3:

@@ -196,6 +196,37 @@ def test_fast_dst_grid_vs_oracle():
         o.close()
 
 
+def test_fused_inverse_transform_unpack_bitwise():
+    """k_dst64_unpack (inverse row transform + modes -> layers + boundary PV in one launch) against
+    the separate k_dst64 / k_unpack_box (/ k_ocqbdy) launches: same expressions, so bitwise equal --
+    through qgcm_hip_steps and through the one-for-one entry points ocinvq + ocqbdy."""
+    import os
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("box_med")
+    mf = OceanModel(cfg)
+    os.environ["QGCM_HIP_NO_FUSED_UNPACK"] = "1"
+    try:
+        ms = OceanModel(cfg)
+    finally:
+        del os.environ["QGCM_HIP_NO_FUSED_UNPACK"]
+    try:
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        for mod in (mf, ms):
+            mod.set_p(po, 0.99 * po)
+            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+            mod.steps(27, s0=1)
+            for _ in range(3):
+                mod.qgostep(); mod.ocinvq(); mod.ocqbdy()
+        for f, x, y in zip(FIELDS, mf.get_state(), ms.get_state()):
+            assert np.array_equal(x, y), f
+        assert np.array_equal(mf.get_scalars(), ms.get_scalars())
+    finally:
+        mf.close()
+        ms.close()
+
+
 @pytest.mark.parametrize("name,nranks", [("box_small", 1), ("box_small", 2), ("box_med", 3), ("box_med", 4)])
 def test_y_slab_decomposition_on_one_gpu(name, nranks):
     """The multi-GPU path with all slabs as virtual ranks on this one GPU: the slab
