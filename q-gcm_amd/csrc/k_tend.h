@@ -39,6 +39,107 @@ __device__ __forceinline__ int tend_wrap(int gi, int nxt) {
   return gi;
 }
 
+// tiles cover i = 1..imax, local rows jlo..jmax; what is left (E wall column, N wall row) is edge work
+struct TendTiling {
+  int gx, gy, imax, jmax;
+  int ecol, erow; // 1 if the E wall column / N wall row is peeled off
+  int nedge;      // edge workgroups
+};
+
+template <bool CYC>
+__host__ __device__ __forceinline__ TendTiling tend_tiling(const QgGeom &g) {
+  TendTiling T;
+  const int rows = g.jhi - g.jlo + 1;
+  T.ecol = (!CYC && g.nx % TEND_TX == 1 && g.nx > 1) ? 1 : 0;
+  T.erow = (!CYC && rows % TEND_TY == 1 && rows > 1 && g.jhi + g.joff == g.nyg) ? 1 : 0;
+  T.gx = T.ecol ? g.nx / TEND_TX : (g.nx + TEND_TX - 1) / TEND_TX;
+  T.gy = T.erow ? rows / TEND_TY : (rows + TEND_TY - 1) / TEND_TY;
+  T.imax = T.ecol ? g.nx - 1 : g.nx;
+  T.jmax = T.erow ? g.jhi - 1 : g.jhi;
+  const int npts = T.ecol * rows + T.erow * T.imax;
+  T.nedge = (npts + TEND_NT - 1) / TEND_NT;
+  return T;
+}
+
+// Point-wise part of the step for one p-point and all layers (qgosubs.F:173-219, ocisubs.F:117-139):
+// dq = dqdt of the point (0 outside the interior), d2bot = Del^2(pom) of the bottom layer,
+// qm / qo = old qom / qo of the point.
+template <int NL, bool CYC>
+__device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj, const double *dq, double d2bot,
+                                           const double *qm, const double *qo, double wek, double ent, double ddy) {
+  const long fs = P.g.fstride;
+  const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
+  if (gj + P.g.joff == 1 || gj + P.g.joff == P.g.nyg) {
+    // rows not stepped: the new-qo buffer keeps qo (qgosubs.F:214-219)
+#pragma unroll
+    for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = qo[k];
+    return;
+  }
+  double qdot[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) qdot[k] = dq[k];
+  qdot[0] = dq[0] + P.fohfac[0] * (wek - ent);
+  qdot[1] = dq[1] + P.fohfac[1] * ent;
+  qdot[NL - 1] = qdot[NL - 1] - P.bdrfac * d2bot;
+  double ql[NL];
+  double betay = P.beta * P.yporel[gj - 1];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    double qn = qm[k] + P.tdto * qdot[k]; // qom + tdto*qdot
+    P.qnew[fs * k + o] = qn;
+    ql[k] = qn - betay;
+  }
+  ql[NL - 1] = ql[NL - 1] - ddy;
+  int c = CYC ? gi - 1 : gi - 2;
+  if (c >= 0 && c < P.g.nk) {
+#pragma unroll
+    for (int m = 0; m < NL; ++m) {
+      double qmm = 0.0;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) qmm = qmm + P.ctl2m[k + NL * m] * ql[k];
+      P.wrk[P.g.wstride * m + (long)(gj - 1) * P.g.ldw + c] = P.fnot * qmm;
+    }
+  }
+}
+
+// Edge work of the box ocean: the E wall column (dqdt = 0, qgosubs.F:371,397; Del^2 of the bottom layer by
+// the wall rule :112,125) and the N wall row (not stepped), one point per thread.
+template <int NL>
+__device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTiling &T, int eblock) {
+  const QgGeom &g = P.g;
+  const int rows = g.jhi - g.jlo + 1;
+  const int t = eblock * TEND_NT + (int)threadIdx.x;
+  int gi, gj;
+  if (t < T.ecol * rows) {
+    gi = g.nx;
+    gj = g.jlo + t;
+  } else {
+    const int u = t - T.ecol * rows;
+    if (!T.erow || u >= T.imax) return;
+    gi = 1 + u;
+    gj = g.jhi;
+  }
+  const long fs = g.fstride;
+  const long o = (long)(gj - 1) * g.ldx + (gi - 1);
+  const bool wallrow = (gj + g.joff == 1 || gj + g.joff == g.nyg);
+  double dq[NL], qm[NL], qo[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    dq[k] = 0.0;
+    qm[k] = wallrow ? 0.0 : P.qnew[fs * k + o];
+    qo[k] = wallrow ? P.qo[fs * k + o] : 0.0;
+  }
+  double d2bot = 0.0, wek = 0.0, ent = 0.0, ddy = 0.0;
+  if (!wallrow) { // then gi == nx: E wall column of a stepped row
+    const double *pb = P.pom + fs * (NL - 1) + o;
+    d2bot = P.bcfaco * (pb[-1] - pb[0]);
+    wek = P.wekpo[o];
+    ent = P.entoc[o];
+    ddy = P.ddynoc[o];
+  }
+  tend_point<NL, false>(P, gi, gj, dq, d2bot, qm, qo, wek, ent, ddy);
+}
+
 template <int NL, bool CYC>
 __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   constexpr int TX = TEND_TX, TY = TEND_TY;
@@ -58,11 +159,19 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   const long fs = P.g.fstride;
   const int tid = threadIdx.x;
   // ---- XCD-aware tile numbering ------------------------------------------
-  const int gx = (nx + TX - 1) / TX, gy = (jhi - jlo + 1 + TY - 1) / TY;
+  // Box grids have nx = 64*g + 1 columns and (whole basin) 8*h + 1 rows: the last column and the last
+  // row are walls whose update is point-wise (no stencil), so they are peeled off into a few "edge"
+  // workgroups instead of a whole extra column / row of nearly empty tiles (tend_edge below).
+  const TendTiling T = tend_tiling<CYC>(P.g);
+  const int gx = T.gx, gy = T.gy;
   const int ntiles = gx * gy;
   const int per_xcd = (ntiles + 7) / 8;
+  if ((int)blockIdx.x >= 8 * per_xcd) {
+    tend_edge<NL>(P, T, (int)blockIdx.x - 8 * per_xcd);
+    return;
+  }
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (tile >= ntiles || (int)(blockIdx.x >> 3) >= per_xcd) return;
+  if (tile >= ntiles) return;
   const int i0 = (tile % gx) * TX + 1; // first global i of the tile (1-based)
   const int j0 = (tile / gx) * TY + jlo; // first local row of the tile
   const int tx = tid % TX;
@@ -102,7 +211,7 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   for (int r = 0; r < RPT; ++r) {
     int ly = ty0 + r * (TEND_NT / TX);
     int gi = i0 + tx, gj = j0 + ly;
-    bool in = gi <= nx && gj <= jhi;
+    bool in = gi <= T.imax && gj <= T.jmax;
     long o = in ? (long)(gj - 1) * ldx + (gi - 1) : 0;
     bool row = in && (gj + joff == 1 || gj + joff == nyg);
     e_wek[r] = in ? P.wekpo[o] : 0.0;
@@ -213,39 +322,14 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   for (int r = 0; r < RPT; ++r) {
     int ly = ty0 + r * (TEND_NT / TX);
     int gi = i0 + tx, gj = j0 + ly;
-    if (gi > nx || gj > jhi) continue;
-    long o = (long)(gj - 1) * ldx + (gi - 1);
-    if (gj + joff == 1 || gj + joff == nyg) {
-      // rows not stepped: the new-qo buffer keeps qo (qgosubs.F:214-219)
-#pragma unroll
-      for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = e_qo[k][r];
-      continue;
-    }
-    double ent = e_ent[r];
-    double qdot[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) qdot[k] = dq[k][r];
-    qdot[0] = dq[0][r] + P.fohfac[0] * (e_wek[r] - ent);
-    qdot[1] = dq[1][r] + P.fohfac[1] * ent;
-    qdot[NL - 1] = qdot[NL - 1] - P.bdrfac * d2bot[r];
-    double ql[NL];
-    double betay = P.beta * P.yporel[gj - 1];
+    if (gi > T.imax || gj > T.jmax) continue;
+    double dqp[NL], qmp[NL], qop[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      double qn = e_qm[k][r] + P.tdto * qdot[k]; // qom + tdto*qdot
-      P.qnew[fs * k + o] = qn;
-      ql[k] = qn - betay;
+      dqp[k] = dq[k][r];
+      qmp[k] = e_qm[k][r];
+      qop[k] = e_qo[k][r];
     }
-    ql[NL - 1] = ql[NL - 1] - e_ddy[r];
-    int c = CYC ? gi - 1 : gi - 2;
-    if (c >= 0 && c < P.g.nk) {
-#pragma unroll
-      for (int m = 0; m < NL; ++m) {
-        double qm = 0.0;
-#pragma unroll
-        for (int k = 0; k < NL; ++k) qm = qm + P.ctl2m[k + NL * m] * ql[k];
-        P.wrk[P.g.wstride * m + (long)(gj - 1) * P.g.ldw + c] = P.fnot * qm;
-      }
-    }
+    tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
   }
 }

@@ -607,8 +607,9 @@ static int launch_tend(qgcm_hip_ctx *c) {
     P.ah4fac[k] = pr.ah4oc[k] / pr.fnot;
   }
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
-  const int ntiles = ((g.nx + TEND_TX - 1) / TEND_TX) * ((g.jhi - g.jlo + 1 + TEND_TY - 1) / TEND_TY);
-  dim3 grid(8 * ((ntiles + 7) / 8)); // 1-D: the kernel maps blockIdx -> tile per XCD band
+  const TendTiling T = g.cyc ? tend_tiling<true>(g) : tend_tiling<false>(g);
+  const int ntiles = T.gx * T.gy;
+  dim3 grid(8 * ((ntiles + 7) / 8) + T.nedge); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge work
   if (g.cyc) {
     // boundary line sums for the momentum constraints, from the state before the step
     QgCycSumParams S;
