@@ -117,6 +117,24 @@ module qgcm_hip_iface
       real(c_double), intent(inout) :: wrk(*)
       real(c_double), intent(in) :: boc(*)
     end function
+    ! y-slab runs, one process per GPU: rendezvous id (rank 0), communicator, whole distributed steps
+    ! (the library issues the RCCL exchanges itself; include/qgcm_hip.h)
+    integer(c_int) function qgcm_hip_comm_unique_id(id, nbytes) bind(C, name='qgcm_hip_comm_unique_id')
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: id(*)
+      integer(c_int), value :: nbytes
+    end function
+    integer(c_int) function qgcm_hip_comm_init(h, id, nbytes, rank, nranks) bind(C, name='qgcm_hip_comm_init')
+      import :: c_ptr, c_int, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: id(*)
+      integer(c_int), value :: nbytes, rank, nranks
+    end function
+    integer(c_int) function qgcm_hip_slab_steps(h, s0, n) bind(C, name='qgcm_hip_slab_steps')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: s0, n
+    end function
   end interface
 
 contains
