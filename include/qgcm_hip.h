@@ -182,6 +182,34 @@ int qgcm_hip_comm_unique_id(char *id, int nbytes);
 int qgcm_hip_comm_init(qgcm_hip_handle h, const char *id, int nbytes, int rank, int nranks);
 int qgcm_hip_slab_steps(qgcm_hip_handle h, int s0, int n);
 
+/* ---- ocean mixed layer -----------------------------------
+ * `call oml` (src/q-gcm.F:1232; body src/omlsubs.F:47-236 + omladf 244-763) on the device: steps the
+ * mixed-layer temperature on the T grid (nxto,nyto) = (nxpo-1,nypo-1), and produces what the PV path
+ * consumes - entoc on the p grid, xon(1) and (cyclic) enisoc(1)/eninoc(1) - without leaving the GPU.
+ * Only for a handle that owns the whole domain. */
+typedef struct qgcm_hip_oml_params {
+  double hmoc;         /* mixed layer thickness                 (MODULE intrfac, input.params) */
+  double toc1, toc2;   /* toc(1), toc(2)                        (MODULE occonst) */
+  double st2d, st4d;   /* Del-sqd / Del-4th sst diffusivities   (MODULE intrfac) */
+  double ycexp;        /* sst advection coupling coefficient    (MODULE occonst) */
+  double rrcpoc;       /* 1/(rhooc*cpoc), src/q-gcm.F:438       (MODULE radiate) */
+  double tsbdy, tnbdy; /* boundary temperatures of the options below */
+  int sb_hflux;        /* the reference's cpp options sb_hflux / nb_hflux as run-time flags */
+  int nb_hflux;
+} qgcm_hip_oml_params;
+/* allocates the mixed-layer state and switches it on: qgcm_hip_steps then runs oml before qgostep in
+ * every step and averages sst with the other fields (src/q-gcm.F:1345-1351) */
+int qgcm_hip_oml_init(qgcm_hip_handle h, const qgcm_hip_oml_params *p);
+/* sst, sstm (MODULE intrfac), dense (nxto,nyto) Fortran order; NULL = leave unchanged / do not fetch */
+int qgcm_hip_oml_set_state(qgcm_hip_handle h, const double *sst, const double *sstm);
+int qgcm_hip_oml_get_state(qgcm_hip_handle h, double *sst, double *sstm);
+/* fnetoc(nxto,nyto) (intrfac), wekto(nxto,nyto) (ocstate), tauxo, tauyo(nxpo,nypo) (intrfac); NULL = unchanged */
+int qgcm_hip_oml_set_forcing(qgcm_hip_handle h, const double *fnetoc, const double *wekto,
+                             const double *tauxo, const double *tauyo);
+int qgcm_hip_oml(qgcm_hip_handle h);          /* replaces "call oml", src/q-gcm.F:1232 */
+/* entoc(nxpo,nypo) (or NULL) and diag[5] = xon(1), cfraoc, centoc, enisoc(1), eninoc(1); synchronous */
+int qgcm_hip_oml_get_diag(qgcm_hip_handle h, double *entoc, double *diag);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
  * the whole region, measured on the handle's stream. */

@@ -18,10 +18,12 @@
 #    the reference (src/lasubs.f INCLUDEs an absent lapack/ dir); the
 #    image's MKL (/opt/conda/lib/libmkl_rt.so) provides it.
 #
-# usage: build_ref.sh <cfg> <nxta> <nyta> <nxaooc|nxta> <nyaooc> <ndxr> <nlo> <fnot> <beta> <cyclic 0|1>
+# usage: build_ref.sh <cfg> <nxta> <nyta> <nxaooc|nxta> <nyaooc> <ndxr> <nlo> <fnot> <beta> <cyclic 0|1> [extra cpp options]
+#   extra cpp options: e.g. -Dsb_hflux (mixed-layer boundary variants, src/omlsubs.F:405-422,437-454);
+#   the cyclic builds carry -Dnb_hflux as examples/southern_ocean_ocean_only does
 set -euo pipefail
 
-CFG=$1; NXTA=$2; NYTA=$3; NXAOOC=$4; NYAOOC=$5; NDXR=$6; NLO=$7; FNOT=$8; BETA=$9; CYC=${10}
+CFG=$1; NXTA=$2; NYTA=$3; NXAOOC=$4; NYAOOC=$5; NDXR=$6; NLO=$7; FNOT=$8; BETA=$9; CYC=${10}; EXTRA=${11:-}
 
 REF=${QGCM_REFERENCE:-/root/reference}
 SRC=$REF/src
@@ -48,6 +50,7 @@ sed -e "s|^      PARAMETER ( nxta = .*|      PARAMETER ( nxta = $NXTA, nyta = $N
 
 Q="-Docean_only"
 if [ "$CYC" = "1" ]; then Q="-Docean_only -Dcyclic_ocean -Dnb_hflux"; fi
+Q="$Q $EXTRA"
 
 FCB="$FC -ffixed-line-length-132 -O2 -fPIC"
 FCO="$FCB -fopenmp"
@@ -59,12 +62,18 @@ $FCO -c -I"$SRC" "$SRC/intsubs.f"
 $FCO -c -I"$SRC" "$SRC/eigmode.f"
 ( cd "$SRC" && $FCO -c -o "$WRK/fftsubs.o" fftsubs.f ) 2> fftsubs.warn || { cat fftsubs.warn; exit 1; }
 for f in vorsubs qgosubs ocisubs conhoms; do $FCO $Q -c -I"$SRC" "$SRC/$f.F"; done
+# ocean mixed layer: intrfac / radiate data modules + omlsubs.F; the latter without
+# -fopenmp (flang rejects its REDUCTION(-:...) clause)
+$FCO $Q -c -I"$SRC" "$SRC/intrfac_data.F"
+$FCO -c -I"$SRC" "$SRC/radiate_data.F"
+$FCB $Q -c -I"$SRC" "$SRC/omlsubs.F"
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_harness.F90"
+$FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_oml.F90"
 
 $FC -shared -fopenmp -o "$OUT/libqgcm_ref_$CFG.so" \
     parameters_data.o occonst_data.o ochomog_data.o ocstate_data.o monitor_data.o \
     intsubs.o eigmode.o fftsubs.o vorsubs.o qgosubs.o ocisubs.o conhoms.o \
-    qgcm_ref_harness.o \
+    intrfac_data.o radiate_data.o omlsubs.o qgcm_ref_harness.o qgcm_ref_oml.o \
     -L"$MKLDIR" -Wl,--no-as-needed -lmkl_gf_lp64 -lmkl_sequential -lmkl_core -Wl,--as-needed -Wl,-rpath,"$MKLDIR" -Wl,-rpath,/opt/rocm/lib/llvm/lib
 
 echo "built $OUT/libqgcm_ref_$CFG.so"

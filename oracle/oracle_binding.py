@@ -55,6 +55,11 @@ def lib():
         L.qgo_eigmod.argtypes = [C.c_int, dp, dp, C.c_double, dp, dp, dp, dp]
         L.qgo_wekpo_from_tau.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
         L.qgo_set_threads.argtypes = [C.c_int]
+        L.qgo_oml_init.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_double, C.c_int, C.c_double]
+        L.qgo_oml_set.argtypes = [C.c_void_p] + [dp] * 6
+        L.qgo_oml_get.argtypes = [C.c_void_p] + [dp] * 4
+        L.qgo_oml.argtypes = [C.c_void_p]
+        L.qgo_steps_oml.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -233,6 +238,29 @@ class Oracle:
 
     def steps(self, s0, n):
         self.L.qgo_steps(self.h, int(s0), int(n))
+
+    # -- ocean mixed layer (src/omlsubs.F), SURVEY 8 row f1 -------------------
+    def oml_init(self, hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, sb_hflux=0, tsbdy=0.0, nb_hflux=0, tnbdy=0.0):
+        self.L.qgo_oml_init(self.h, hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, int(sb_hflux), tsbdy, int(nb_hflux), tnbdy)
+
+    def oml_set(self, sst, sstm, fnetoc, wekto, tauxo, tauyo):
+        a = [np.asfortranarray(x, dtype=np.float64) for x in (sst, sstm, fnetoc, wekto, tauxo, tauyo)]
+        assert a[0].shape == (self.nx - 1, self.ny - 1) and a[4].shape == (self.nx, self.ny)
+        self.L.qgo_oml_set(self.h, *[_dp(x) for x in a])
+
+    def oml_get(self):
+        sst = np.zeros((self.nx - 1, self.ny - 1), order="F")
+        sstm = np.zeros_like(sst)
+        ent = np.zeros((self.nx, self.ny), order="F")
+        scal = np.zeros(5)
+        self.L.qgo_oml_get(self.h, _dp(sst), _dp(sstm), _dp(ent), _dp(scal))
+        return sst, sstm, ent, scal
+
+    def oml(self):
+        self.L.qgo_oml(self.h)
+
+    def steps_oml(self, s0, n):
+        self.L.qgo_steps_oml(self.h, int(s0), int(n))
 
     def project(self):
         w = self._f3()

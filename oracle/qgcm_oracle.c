@@ -41,6 +41,12 @@ struct qgo_ctx {
   double *xinhom, *invcoef;
   /* scratch */
   double *d2p, *d4p, *dqdt, *wrk;
+  /* ocean mixed layer (src/omlsubs.F), SURVEY 8 row f1 */
+  int oml_on, sb_hflux, nb_hflux;
+  double hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, tsbdy, tnbdy;
+  double *sst, *sstm, *fnetoc, *wekto, *tauxo, *tauyo; /* T grid (nxto,nyto) x4, p grid x2 */
+  double *omrhs, *omd2t, *omxfo;                        /* scratch */
+  double cfraoc, centoc;
 };
 
 #define IX(i, j) ((size_t)((i)-1) + (size_t)nx * (size_t)((j)-1))
@@ -718,7 +724,8 @@ void qgo_destroy(qgo_ctx *c) {
                     c->pch1oc, c->pch2oc, c->pbhoc, c->aipcho, c->hc1soc, c->hc2soc, c->hc1noc, c->hc2noc,
                     c->ocncs, c->ocncn, c->ocncsp, c->ocncnp, c->enisoc, c->eninoc, c->ajisoc, c->ajinoc,
                     c->ap3soc, c->ap3noc, c->ap5soc, c->ap5noc, c->xinhom, c->invcoef, c->d2p, c->d4p,
-                    c->dqdt, c->wrk};
+                    c->dqdt, c->wrk, c->sst, c->sstm, c->fnetoc, c->wekto, c->tauxo, c->tauyo,
+                    c->omrhs, c->omd2t, c->omxfo};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
   free(c->ipivch);
   free(c);
@@ -1336,4 +1343,237 @@ void qgo_wekpo_from_tau(int nx, int ny, int cyclic, double dxo, double fnot, con
     wekpo[IX(nx, ny)] = WT(nxt, nyt);
   }
 #undef WT
+}
+
+
+/* ================================================================== */
+/* Ocean mixed layer: oml + omladf, src/omlsubs.F:47-236, 244-763      */
+/* (SURVEY 8 row f1).  T-grid fields are (nxto,nyto), element (i,j) at  */
+/* (i-1) + nxto*(j-1).                                                  */
+/* ================================================================== */
+void qgo_oml_init(qgo_ctx *c, double hmoc, double toc1, double toc2, double st2d, double st4d, double ycexp,
+                  double rrcpoc, int sb_hflux, double tsbdy, int nb_hflux, double tnbdy) {
+  size_t nt = (size_t)c->nxt * (c->ny - 1), np = (size_t)c->nx * c->ny;
+  c->oml_on = 1;
+  c->hmoc = hmoc; c->toc1 = toc1; c->toc2 = toc2; c->st2d = st2d; c->st4d = st4d; c->ycexp = ycexp;
+  c->rrcpoc = rrcpoc; c->sb_hflux = sb_hflux; c->tsbdy = tsbdy; c->nb_hflux = nb_hflux; c->tnbdy = tnbdy;
+  if (!c->sst) {
+    c->sst = dalloc(nt); c->sstm = dalloc(nt); c->fnetoc = dalloc(nt); c->wekto = dalloc(nt);
+    c->tauxo = dalloc(np); c->tauyo = dalloc(np);
+    c->omrhs = dalloc(nt); c->omd2t = dalloc(nt); c->omxfo = dalloc(nt);
+  }
+}
+
+void qgo_oml_set(qgo_ctx *c, const double *sst, const double *sstm, const double *fnetoc, const double *wekto,
+                 const double *tauxo, const double *tauyo) {
+  size_t nt = (size_t)c->nxt * (c->ny - 1) * sizeof(double), np = (size_t)c->nx * c->ny * sizeof(double);
+  if (sst) memcpy(c->sst, sst, nt);
+  if (sstm) memcpy(c->sstm, sstm, nt);
+  if (fnetoc) memcpy(c->fnetoc, fnetoc, nt);
+  if (wekto) memcpy(c->wekto, wekto, nt);
+  if (tauxo) memcpy(c->tauxo, tauxo, np);
+  if (tauyo) memcpy(c->tauyo, tauyo, np);
+}
+
+/* scal = xon(1), cfraoc, centoc, enisoc(1), eninoc(1) */
+void qgo_oml_get(qgo_ctx *c, double *sst, double *sstm, double *entoc, double *scal) {
+  size_t nt = (size_t)c->nxt * (c->ny - 1) * sizeof(double), np = (size_t)c->nx * c->ny * sizeof(double);
+  if (sst) memcpy(sst, c->sst, nt);
+  if (sstm) memcpy(sstm, c->sstm, nt);
+  if (entoc) memcpy(entoc, c->entoc, np);
+  if (scal) {
+    scal[0] = c->xon[0]; scal[1] = c->cfraoc; scal[2] = c->centoc;
+    scal[3] = c->cyclic ? c->enisoc[0] : 0.0; scal[4] = c->cyclic ? c->eninoc[0] : 0.0;
+  }
+}
+
+/* del2t(i,j) of the lagged sst with the boundary variants of src/omlsubs.F:297-300 (W), 331-346 (E),
+ * 403-422 (S), 437-454 (N), 466-647 (corners); the operand order of every case is the reference's. */
+static double oml_del2t(const qgo_ctx *c, int i, int j) {
+  const int nxt = c->nxt, nyt = c->ny - 1, cyc = c->cyclic;
+  const double *T = c->sstm;
+#define TM(ii, jj) T[(size_t)((ii)-1) + (size_t)nxt * ((jj)-1)]
+  const int hasW = (i > 1) || cyc, hasE = (i < nxt) || cyc;
+  const double w = hasW ? TM(i > 1 ? i - 1 : nxt, j) : 0.0, e = hasE ? TM(i < nxt ? i + 1 : 1, j) : 0.0;
+  const double cc = TM(i, j);
+  double acc = 0.0, n = 0.0;
+  int first = 1;
+#define ADD(v) do { acc = first ? (v) : acc + (v); first = 0; n += 1.0; } while (0)
+  if (j == 1) { /* W, E, N, tsbdy */
+    if (hasW) ADD(w);
+    if (hasE) ADD(e);
+    ADD(TM(i, 2));
+    if (c->sb_hflux) ADD(c->tsbdy);
+    return acc - n * cc;
+  }
+  if (j == nyt) {
+    if (cyc && i == nxt && c->nb_hflux) /* :630-631: tnbdy is added after the -4 sstm term */
+      return TM(i, j - 1) + w + e - 4.0 * cc + c->tnbdy;
+    ADD(TM(i, j - 1)); /* S, W, tnbdy, E */
+    if (hasW) ADD(w);
+    if (c->nb_hflux) ADD(c->tnbdy);
+    if (hasE) ADD(e);
+    return acc - n * cc;
+  }
+  ADD(TM(i, j - 1)); /* S, W, E, N */
+  if (hasW) ADD(w);
+  if (hasE) ADD(e);
+  ADD(TM(i, j + 1));
+  return acc - n * cc;
+#undef ADD
+#undef TM
+}
+
+/* omladf, src/omlsubs.F:244-763: advective + diffusive right-hand side in c->omrhs */
+static void omladf(qgo_ctx *c) {
+  const int nx = c->nx, nxt = c->nxt, nyt = c->ny - 1, cyc = c->cyclic;
+  const double rdxof0 = 1.0 / (c->dxo * c->fnot), hdxom1 = 0.5 / c->dxo;
+  const double uvgfac = c->ycexp * rdxof0, rhf0hm = 0.5 / (c->fnot * c->hmoc);
+  const double d2tfac = c->st2d * c->dxom2, d4tfac = c->st4d * (c->dxom2 * c->dxom2);
+  const double *po = c->po, *tx = c->tauxo, *ty = c->tauyo, *S = c->sst;
+  double *rhs = c->omrhs, *D = c->omd2t;
+#define PO1(ii, jj) po[(size_t)((ii)-1) + (size_t)nx * ((jj)-1)]
+#define TX(ii, jj) tx[(size_t)((ii)-1) + (size_t)nx * ((jj)-1)]
+#define TY(ii, jj) ty[(size_t)((ii)-1) + (size_t)nx * ((jj)-1)]
+#define ST(ii, jj) S[(size_t)((ii)-1) + (size_t)nxt * ((jj)-1)]
+#define UF(ii, jj) (-uvgfac * (PO1(ii, (jj) + 1) - PO1(ii, jj)) + rhf0hm * (TY(ii, (jj) + 1) + TY(ii, jj)))
+#define VF(ii, jj) (uvgfac * (PO1((ii) + 1, jj) - PO1(ii, jj)) - rhf0hm * (TX((ii) + 1, jj) + TX(ii, jj)))
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= nyt; ++j)
+    for (int i = 1; i <= nxt; ++i) {
+      double um, tm, up, tp;
+      if (i == 1 && !cyc) { um = 0.0; tm = 0.0; }
+      else { um = UF(i, j); tm = ST(i > 1 ? i - 1 : nxt, j) + ST(i, j); }
+      if (i == nxt && !cyc) { up = 0.0; tp = 0.0; }
+      else { up = UF(i + 1, j); tp = ST(i, j) + ST(i < nxt ? i + 1 : 1, j); }
+      const double hxadv = hdxom1 * (up * tp - um * tm);
+      double hyadv;
+      if (j == 1) {
+        const double vp = VF(i, 2), tp2 = ST(i, 1) + ST(i, 2);
+        if (c->sb_hflux) {
+          const double vm = -rhf0hm * (TX(i + 1, 1) + TX(i, 1)), tm2 = ST(i, 1) + c->tsbdy;
+          hyadv = hdxom1 * (vp * tp2 - vm * tm2);
+        } else hyadv = hdxom1 * (vp * tp2);
+      } else if (j == nyt) {
+        const double vm = VF(i, nyt), tm2 = ST(i, nyt - 1) + ST(i, nyt);
+        if (c->nb_hflux) {
+          const double vp = -rhf0hm * (TX(i + 1, nyt + 1) + TX(i, nyt + 1)), tp2 = ST(i, nyt) + c->tnbdy;
+          hyadv = hdxom1 * (vp * tp2 - vm * tm2);
+        } else hyadv = hdxom1 * (-vm * tm2);
+      } else {
+        const double vm = VF(i, j), vp = VF(i, j + 1);
+        hyadv = hdxom1 * (vp * (ST(i, j + 1) + ST(i, j)) - vm * (ST(i, j) + ST(i, j - 1)));
+      }
+      rhs[(size_t)(i - 1) + (size_t)nxt * (j - 1)] = -(hxadv + hyadv);
+      D[(size_t)(i - 1) + (size_t)nxt * (j - 1)] = oml_del2t(c, i, j);
+    }
+  /* Del-sqd and Del-4th terms, :733-759; dummy columns :349-357 (box: copy of the edge, cyclic: wrap) */
+#define DD(ii, jj) D[(size_t)(((ii) < 1 ? (cyc ? nxt : 1) : ((ii) > nxt ? (cyc ? 1 : nxt) : (ii))) - 1) + (size_t)nxt * ((jj)-1)]
+#pragma omp parallel for schedule(static)
+  for (int j = 1; j <= nyt; ++j)
+    for (int i = 1; i <= nxt; ++i) {
+      double *r = &rhs[(size_t)(i - 1) + (size_t)nxt * (j - 1)];
+      if (j == 1) *r = *r + d2tfac * DD(i, 1) - d4tfac * (DD(i - 1, 1) + DD(i + 1, 1) + DD(i, 2) - 3.0 * DD(i, 1));
+      else if (j == nyt)
+        *r = *r + d2tfac * DD(i, nyt) - d4tfac * (DD(i, nyt - 1) + DD(i - 1, nyt) + DD(i + 1, nyt) - 3.0 * DD(i, nyt));
+      else
+        *r = *r + d2tfac * DD(i, j) - d4tfac * (DD(i, j - 1) + DD(i - 1, j) + DD(i + 1, j) + DD(i, j + 1) - 4.0 * DD(i, j));
+    }
+#undef DD
+#undef PO1
+#undef TX
+#undef TY
+#undef ST
+#undef UF
+#undef VF
+}
+
+/* oml, src/omlsubs.F:47-236 */
+void qgo_oml(qgo_ctx *c) {
+  const int nx = c->nx, ny = c->ny, nxt = c->nxt, nyt = c->ny - 1, cyc = c->cyclic;
+  const double hmoinv = 1.0 / c->hmoc, dtoinv = 1.0 / (c->toc1 - c->toc2), entfac = c->hmoc * dtoinv / c->tdto;
+  const double ocnorm = 1.0 / ((double)nxt * (double)nyt);
+  double *xfo = c->omxfo, *ent = c->entoc;
+  omladf(c);
+  double cfrasm = 0.0, centsm = 0.0;
+  for (int j = 1; j <= nyt; ++j)
+    for (int i = 1; i <= nxt; ++i) {
+      const size_t o = (size_t)(i - 1) + (size_t)nxt * (j - 1);
+      const double diabat = 0.5 * c->wekto[o] * (c->sstm[o] + c->toc1);
+      double sstnew = c->sstm[o] + c->tdto * (c->omrhs[o] + hmoinv * (c->rrcpoc * c->fnetoc[o] + diabat));
+      const double xfoent = -(0.5 * dtoinv) * c->wekto[o] * (c->sstm[o] - c->toc1);
+      const double dtonew = c->toc1 - sstnew;
+      const double coneno = entfac * fmax(0.0, dtonew);
+      xfo[o] = xfoent - coneno;
+      sstnew = sstnew + fmax(0.0, dtonew);
+      cfrasm = cfrasm + (0.5 - copysign(0.5, -dtonew));
+      centsm = centsm - coneno;
+      c->sstm[o] = c->sst[o];
+      c->sst[o] = sstnew;
+    }
+  double xfosum = 0.0;
+  for (int j = 1; j <= nyt; ++j) {
+    double xfsi = 0.0;
+    for (int i = 1; i <= nxt; ++i) xfsi = xfsi + xfo[(size_t)(i - 1) + (size_t)nxt * (j - 1)];
+    xfosum = xfosum + xfsi;
+  }
+  for (size_t o = 0; o < (size_t)nxt * nyt; ++o) xfo[o] = xfo[o] - xfosum * ocnorm;
+#define XF(ii, jj) xfo[(size_t)((ii)-1) + (size_t)nxt * ((jj)-1)]
+#define EN(ii, jj) ent[(size_t)((ii)-1) + (size_t)nx * ((jj)-1)]
+  for (int j = 2; j <= ny - 1; ++j)
+    for (int i = 2; i <= nx - 1; ++i) EN(i, j) = 0.25 * (XF(i - 1, j - 1) + XF(i, j - 1) + XF(i - 1, j) + XF(i, j));
+  for (int i = 2; i <= nx - 1; ++i) {
+    EN(i, 1) = 0.5 * (XF(i - 1, 1) + XF(i, 1));
+    EN(i, ny) = 0.5 * (XF(i - 1, nyt) + XF(i, nyt));
+  }
+  if (cyc) {
+    for (int j = 2; j <= ny - 1; ++j) {
+      EN(1, j) = 0.25 * (XF(nxt, j - 1) + XF(1, j - 1) + XF(nxt, j) + XF(1, j));
+      EN(nx, j) = EN(1, j);
+    }
+    EN(1, 1) = 0.5 * (XF(nxt, 1) + XF(1, 1));
+    EN(1, ny) = 0.5 * (XF(nxt, nyt) + XF(1, nyt));
+    EN(nx, 1) = EN(1, 1);
+    EN(nx, ny) = EN(1, ny);
+  } else {
+    for (int j = 2; j <= ny - 1; ++j) {
+      EN(1, j) = 0.5 * (XF(1, j - 1) + XF(1, j));
+      EN(nx, j) = 0.5 * (XF(nxt, j - 1) + XF(nxt, j));
+    }
+    EN(1, 1) = XF(1, 1);
+    EN(nx, 1) = XF(nxt, 1);
+    EN(1, ny) = XF(1, nyt);
+    EN(nx, ny) = XF(nxt, nyt);
+  }
+  c->cfraoc = cfrasm * ocnorm;
+  c->centoc = centsm * c->dxo * c->dyo;
+  c->xon[0] = qgo_xintp(ent, nx, ny);
+  c->xon[0] = c->xon[0] * c->dxo * c->dyo;
+  if (cyc) {
+    double ensums = 0.5 * EN(1, 1), ensumn = 0.5 * EN(1, ny);
+    for (int i = 2; i <= nx - 1; ++i) {
+      ensums = ensums + EN(i, 1);
+      ensumn = ensumn + EN(i, ny);
+    }
+    ensums = ensums + 0.5 * EN(nx, 1);
+    ensumn = ensumn + 0.5 * EN(nx, ny);
+    c->enisoc[0] = c->dxo * ensums;
+    c->eninoc[0] = c->dxo * ensumn;
+  }
+#undef XF
+#undef EN
+}
+
+/* src/q-gcm.F:1232-1249 + 1328-1366 with the mixed layer on */
+void qgo_steps_oml(qgo_ctx *c, int s0, int n) {
+  for (int s = s0; s < s0 + n; ++s) {
+    qgo_oml(c);
+    qgo_qgostep(c);
+    qgo_ocinvq(c);
+    qgo_ocqbdy(c);
+    if ((s - 1) % 25 == 0) {
+      qgo_lf_average(c);
+      for (size_t o = 0; o < (size_t)c->nxt * (c->ny - 1); ++o) c->sst[o] = 0.5 * (c->sst[o] + c->sstm[o]);
+    }
+  }
 }

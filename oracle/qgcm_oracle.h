@@ -74,6 +74,17 @@ void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
 void qgo_wekpo_from_tau(int nxpo, int nypo, int cyclic, double dxo, double fnot,
                         const double *tauxo, const double *tauyo, double *wekto, double *wekpo);
 
+/* ocean mixed layer oml / omladf (src/omlsubs.F:47-236, 244-763), SURVEY 8 row f1.
+ * T-grid arrays are (nxto,nyto) = (nxpo-1, nypo-1); sb_hflux / nb_hflux are the reference's compile-time
+ * boundary options as run-time flags.  qgo_oml_get: scal = xon(1), cfraoc, centoc, enisoc(1), eninoc(1). */
+void qgo_oml_init(qgo_ctx *c, double hmoc, double toc1, double toc2, double st2d, double st4d, double ycexp,
+                  double rrcpoc, int sb_hflux, double tsbdy, int nb_hflux, double tnbdy);
+void qgo_oml_set(qgo_ctx *c, const double *sst, const double *sstm, const double *fnetoc, const double *wekto,
+                 const double *tauxo, const double *tauyo);
+void qgo_oml_get(qgo_ctx *c, double *sst, double *sstm, double *entoc, double *scal);
+void qgo_oml(qgo_ctx *c);
+void qgo_steps_oml(qgo_ctx *c, int s0, int n); /* oml, qgostep, ocinvq, ocqbdy (+ averaging incl. sst) */
+
 #ifdef __cplusplus
 }
 #endif

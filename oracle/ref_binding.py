@@ -24,6 +24,9 @@ CONFIGS = {
     "box_tiny": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0),
     "box_small": (12, 10, 6, 5, 16, 3, "9.37456D-05", "1.75360D-11", 0),
     "box_tiny2": (8, 8, 5, 4, 6, 2, "5.92D-05", "2.08D-11", 0),
+    # box_tiny compiled with the specified-temperature southern boundary of the mixed layer (-Dsb_hflux,
+    # as examples/double_gyre_coupled; src/omlsubs.F:405-422)
+    "box_tiny_sb": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsb_hflux"),
     "cyc_tiny": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1),
     "cyc_small": (6, 10, "nxta", 4, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
     "box_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0),
@@ -133,6 +136,37 @@ class RefLib:
         e = self._f2() if entoc is None else np.asfortranarray(entoc, dtype=np.float64)
         x = np.zeros(self.nl - 1) if xon is None else np.ascontiguousarray(xon, dtype=np.float64)
         self.lib.ref_set_forcing(_dp(w), _dp(e), _dp(x))
+
+    # -- ocean mixed layer (src/omlsubs.F), SURVEY 8 row f1 -------------------
+    def oml_flags(self):
+        sb, nb = C.c_int(), C.c_int()
+        self.lib.ref_oml_flags(C.byref(sb), C.byref(nb))
+        return sb.value, nb.value
+
+    def oml_init(self, hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, tsbdy, tnbdy):
+        self.lib.ref_oml_init.argtypes = [C.c_double] * 9
+        self.lib.ref_oml_init(hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, tsbdy, tnbdy)
+
+    def oml_set(self, sst, sstm, fnetoc, wekto, tauxo, tauyo):
+        a = [np.asfortranarray(x, dtype=np.float64) for x in (sst, sstm, fnetoc, wekto, tauxo, tauyo)]
+        assert a[0].shape == (self.nx - 1, self.ny - 1) and a[4].shape == (self.nx, self.ny)
+        self.lib.ref_oml_set(*[_dp(x) for x in a])
+
+    def oml_get(self):
+        """sst, sstm (T grid), entoc (p grid), (xon(1), cfraoc, centoc, enisoc(1), eninoc(1))."""
+        sst = np.zeros((self.nx - 1, self.ny - 1), order="F")
+        sstm = np.zeros_like(sst)
+        ent = self._f2()
+        scal = np.zeros(5)
+        self.lib.ref_oml_get(_dp(sst), _dp(sstm), _dp(ent), _dp(scal))
+        return sst, sstm, ent, scal
+
+    def oml(self):
+        run_big_stack(self.lib.ref_oml)
+
+    def steps_oml(self, s0, n):
+        self.lib.ref_steps_oml.argtypes = [C.c_int, C.c_int]
+        run_big_stack(self.lib.ref_steps_oml, int(s0), int(n))
 
     def set_cyc_forcing(self, txis, txin, enis=None, enin=None):
         es = np.zeros(self.nl - 1) if enis is None else np.ascontiguousarray(enis, dtype=np.float64)

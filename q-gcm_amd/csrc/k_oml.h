@@ -1,0 +1,260 @@
+// k_oml.h - ocean mixed layer on the device.
+//
+// Replaces `call oml` of the reference main program (src/q-gcm.F:1232):
+//   omladf  advective + diffusive tendency of the mixed-layer temperature, second-order C-grid advection by the
+//           geostrophic + Ekman velocity of the top layer, Del^2 and Del^4 diffusion of the lagged sst with
+//           no-flux walls or specified boundary temperature (sb_hflux / nb_hflux)   src/omlsubs.F:244-763
+//   oml     leapfrog step of sst (7.11), entrainment at T points (7.12), convective adjustment (7.13),
+//           removal of the mean entrainment, averaging onto the p grid (entoc), xon(1) = area integral,
+//           cyclic: boundary line integrals enisoc(1) / eninoc(1)                    src/omlsubs.F:47-236
+// Without it the host would need po(:,:,1) down and entoc up over PCIe every step (2 x 7.4 MB at 5 km).
+//
+// Three launches:
+//   k_oml_step   one thread per T point: rhs (every expression in the reference's operand order, contraction
+//                off => sst is bitwise the reference's), new sst into the spare buffer (the sst buffers
+//                rotate: new -> sst, sst -> sstm), raw entrainment xfo, per-workgroup partial sums
+//   k_oml_entoc  every workgroup re-reduces the partials in the same fixed order (no extra launch, same mean
+//                everywhere), entoc = average of (xfo - mean) onto the p points, partials of xintp / line sums
+//   k_oml_final  one workgroup: xon(1), enisoc(1), eninoc(1), monitors cfraoc / centoc
+// The reference's sums run over j then i (and thread-dependent under OpenMP); here the order is fixed but
+// different, so the mean entrainment agrees to rounding (tests: 1e-13 of max|xfo|), everything else bitwise.
+// Algorithmic traffic: read sstm, sst, po(1), tauxo, tauyo, fnetoc, wekto (7) + write sst, xfo (2) in the first
+// kernel, read xfo + write entoc (2) in the second: 11 N * 8 B = 81 MB at 5 km.
+#pragma once
+#include "qgcm_dev.h"
+
+#define OML_TX 64
+#define OML_TY 4
+#define OML_NT (OML_TX * OML_TY)
+#define OML_RPT 4 // rows per thread in k_oml_step
+
+struct QgOmlParams {
+  int nxt, nyt, nx, ny, cyc, sb, nb;
+  int ldt, ldx;
+  const double *sst, *sstm; // T grid, pitch ldt
+  double *sstn;             // new sst (spare buffer)
+  const double *fnet, *wekto;
+  double *xfo;
+  const double *po1, *taux, *tauy; // p grid, pitch ldx (top layer of po)
+  double *entoc;
+  double *partA; // (3, nblkA): xfo sum, cfrasm, centsm per workgroup of k_oml_step
+  double *partB; // (3, nblkB): xintp sum, S / N line sums per workgroup of k_oml_entoc
+  int nblkA, nblkB;
+  QgScalars *sc;
+  double *diag; // cfraoc, centoc
+  double uvgfac, rhf0hm, hdxom1, d2tfac, d4tfac, hmoinv, dtoinv, entfac, tdto, rrcpoc, toc1, tsbdy, tnbdy, ocnorm, dxo, dyo;
+};
+
+// del2t(i,j) of the lagged sst, boundary variants of src/omlsubs.F:297-300 (W), 331-346 (E), 403-422 (S),
+// 437-454 (N), 466-647 (corners); the operand order of every case is the reference's.
+__device__ __forceinline__ double oml_del2t(const QgOmlParams &P, int i, int j) {
+  const int nxt = P.nxt, nyt = P.nyt;
+  const double *T = P.sstm;
+  const long ld = P.ldt;
+  const bool hasW = (i > 1) || P.cyc, hasE = (i < nxt) || P.cyc;
+  const double cc = T[(long)(j - 1) * ld + (i - 1)];
+  const double w = hasW ? T[(long)(j - 1) * ld + ((i > 1 ? i - 1 : nxt) - 1)] : 0.0;
+  const double e = hasE ? T[(long)(j - 1) * ld + ((i < nxt ? i + 1 : 1) - 1)] : 0.0;
+  double acc, n;
+  if (j == 1) { // W, E, N, tsbdy
+    const double nn = T[(long)j * ld + (i - 1)];
+    if (hasW) { acc = w; n = 1.0; if (hasE) { acc = acc + e; n = 2.0; } }
+    else { acc = e; n = 1.0; } // a row has at least one x neighbour
+    acc = acc + nn; n += 1.0;
+    if (P.sb) { acc = acc + P.tsbdy; n += 1.0; }
+    return acc - n * cc;
+  }
+  const double s = T[(long)(j - 2) * ld + (i - 1)];
+  if (j == nyt) {
+    if (P.cyc && i == nxt && P.nb) return s + w + e - 4.0 * cc + P.tnbdy; // :630-631
+    acc = s; n = 1.0; // S, W, tnbdy, E
+    if (hasW) { acc = acc + w; n += 1.0; }
+    if (P.nb) { acc = acc + P.tnbdy; n += 1.0; }
+    if (hasE) { acc = acc + e; n += 1.0; }
+    return acc - n * cc;
+  }
+  acc = s; n = 1.0; // S, W, E, N
+  if (hasW) { acc = acc + w; n += 1.0; }
+  if (hasE) { acc = acc + e; n += 1.0; }
+  acc = acc + T[(long)j * ld + (i - 1)]; n += 1.0;
+  return acc - n * cc;
+}
+
+// del2t with the dummy columns of src/omlsubs.F:349-357 (box: copy of the edge column, cyclic: wrap)
+__device__ __forceinline__ double oml_del2t_x(const QgOmlParams &P, int i, int j) {
+  if (i < 1) i = P.cyc ? P.nxt : 1;
+  else if (i > P.nxt) i = P.cyc ? 1 : P.nxt;
+  return oml_del2t(P, i, j);
+}
+
+__device__ inline double oml_block_sum(double v, double *red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int off = OML_NT / 2; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// grid: (ceil(nxt/64), ceil(nyt/16)), block 256 = 64 x 4; thread rows j0 + ty + 4 r
+__global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
+  __shared__ double red[OML_NT];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * OML_TX + (tid % OML_TX) + 1;
+  const int nxt = P.nxt, nyt = P.nyt;
+  const long ldt = P.ldt, ldx = P.ldx;
+  const double uvgfac = P.uvgfac, rhf0hm = P.rhf0hm, hdxom1 = P.hdxom1;
+  double sxfo = 0.0, scfr = 0.0, scen = 0.0;
+#define PO1(ii, jj) P.po1[(long)((jj)-1) * ldx + ((ii)-1)]
+#define TXo(ii, jj) P.taux[(long)((jj)-1) * ldx + ((ii)-1)]
+#define TYo(ii, jj) P.tauy[(long)((jj)-1) * ldx + ((ii)-1)]
+#define ST(ii, jj) P.sst[(long)((jj)-1) * ldt + ((ii)-1)]
+#define UF(ii, jj) (-uvgfac * (PO1(ii, (jj) + 1) - PO1(ii, jj)) + rhf0hm * (TYo(ii, (jj) + 1) + TYo(ii, jj)))
+#define VF(ii, jj) (uvgfac * (PO1((ii) + 1, jj) - PO1(ii, jj)) - rhf0hm * (TXo((ii) + 1, jj) + TXo(ii, jj)))
+#pragma unroll
+  for (int r = 0; r < OML_RPT; ++r) {
+    const int j = blockIdx.y * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + 1;
+    if (i > nxt || j > nyt) continue;
+    // ---- advection, src/omlsubs.F:281-346 (rows), 370-456 (S/N rows), 458-700 (corners) ----
+    double um, tm, up, tp;
+    if (i == 1 && !P.cyc) { um = 0.0; tm = 0.0; }
+    else { um = UF(i, j); tm = ST(i > 1 ? i - 1 : nxt, j) + ST(i, j); }
+    if (i == nxt && !P.cyc) { up = 0.0; tp = 0.0; }
+    else { up = UF(i + 1, j); tp = ST(i, j) + ST(i < nxt ? i + 1 : 1, j); }
+    const double hxadv = hdxom1 * (up * tp - um * tm);
+    double hyadv;
+    if (j == 1) {
+      const double vp = VF(i, 2), tp2 = ST(i, 1) + ST(i, 2);
+      if (P.sb) {
+        const double vm = -rhf0hm * (TXo(i + 1, 1) + TXo(i, 1)), tm2 = ST(i, 1) + P.tsbdy;
+        hyadv = hdxom1 * (vp * tp2 - vm * tm2);
+      } else hyadv = hdxom1 * (vp * tp2);
+    } else if (j == nyt) {
+      const double vm = VF(i, nyt), tm2 = ST(i, nyt - 1) + ST(i, nyt);
+      if (P.nb) {
+        const double vp = -rhf0hm * (TXo(i + 1, nyt + 1) + TXo(i, nyt + 1)), tp2 = ST(i, nyt) + P.tnbdy;
+        hyadv = hdxom1 * (vp * tp2 - vm * tm2);
+      } else hyadv = hdxom1 * (-vm * tm2);
+    } else {
+      const double vm = VF(i, j), vp = VF(i, j + 1);
+      hyadv = hdxom1 * (vp * (ST(i, j + 1) + ST(i, j)) - vm * (ST(i, j) + ST(i, j - 1)));
+    }
+    double rhs = -(hxadv + hyadv);
+    // ---- diffusion, src/omlsubs.F:733-759 ----
+    const double dc = oml_del2t(P, i, j), dw = oml_del2t_x(P, i - 1, j), de = oml_del2t_x(P, i + 1, j);
+    if (j == 1) rhs = rhs + P.d2tfac * dc - P.d4tfac * (dw + de + oml_del2t(P, i, 2) - 3.0 * dc);
+    else if (j == nyt) rhs = rhs + P.d2tfac * dc - P.d4tfac * (oml_del2t(P, i, nyt - 1) + dw + de - 3.0 * dc);
+    else rhs = rhs + P.d2tfac * dc - P.d4tfac * (oml_del2t(P, i, j - 1) + dw + de + oml_del2t(P, i, j + 1) - 4.0 * dc);
+    // ---- oml, src/omlsubs.F:101-128 ----
+    const long o = (long)(j - 1) * ldt + (i - 1);
+    const double sm = P.sstm[o], wk = P.wekto[o];
+    const double diabat = 0.5 * wk * (sm + P.toc1);
+    double sstnew = sm + P.tdto * (rhs + P.hmoinv * (P.rrcpoc * P.fnet[o] + diabat));
+    const double xfoent = -(0.5 * P.dtoinv) * wk * (sm - P.toc1);
+    const double dtonew = P.toc1 - sstnew;
+    const double coneno = P.entfac * fmax(0.0, dtonew);
+    const double xf = xfoent - coneno;
+    sstnew = sstnew + fmax(0.0, dtonew);
+    P.xfo[o] = xf;
+    P.sstn[o] = sstnew;
+    sxfo += xf;
+    scfr += (0.5 - copysign(0.5, -dtonew));
+    scen -= coneno;
+  }
+#undef PO1
+#undef TXo
+#undef TYo
+#undef ST
+#undef UF
+#undef VF
+  const int b = blockIdx.y * gridDim.x + blockIdx.x;
+  const double t0 = oml_block_sum(sxfo, red, tid), t1 = oml_block_sum(scfr, red, tid), t2 = oml_block_sum(scen, red, tid);
+  if (tid == 0) {
+    P.partA[b] = t0;
+    P.partA[P.nblkA + b] = t1;
+    P.partA[2 * P.nblkA + b] = t2;
+  }
+}
+
+// grid: (ceil(nx/64), ceil(ny/4)), block 256 = 64 x 4, one p point per thread
+__global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
+  __shared__ double red[OML_NT];
+  const int tid = threadIdx.x;
+  // mean entrainment: the same fixed-order reduction of the partials in every workgroup
+  double s = 0.0;
+  for (int k = tid; k < P.nblkA; k += OML_NT) s += P.partA[k];
+  const double xmean = oml_block_sum(s, red, tid) * P.ocnorm; // xfosum*ocnorm, src/omlsubs.F:153
+  const int i = blockIdx.x * OML_TX + (tid % OML_TX) + 1;
+  const int j = blockIdx.y * OML_TY + (tid / OML_TX) + 1;
+  const int nx = P.nx, ny = P.ny, nxt = P.nxt, nyt = P.nyt;
+  const long ldt = P.ldt;
+  double wsum = 0.0, lsS = 0.0, lsN = 0.0;
+  if (i <= nx && j <= ny) {
+#define XF(ii, jj) (P.xfo[(long)((jj)-1) * ldt + ((ii)-1)] - xmean)
+    double en;
+    const bool xin = (i >= 2 && i <= nx - 1), yin = (j >= 2 && j <= ny - 1);
+    if (xin && yin) en = 0.25 * (XF(i - 1, j - 1) + XF(i, j - 1) + XF(i - 1, j) + XF(i, j)); // :162-163
+    else if (xin) {
+      const int jt = (j == 1) ? 1 : nyt;
+      en = 0.5 * (XF(i - 1, jt) + XF(i, jt)); // :171-172
+    } else if (P.cyc) { // :178-189: W column from the wrapped T cells, E column = W column
+      if (yin) en = 0.25 * (XF(nxt, j - 1) + XF(1, j - 1) + XF(nxt, j) + XF(1, j));
+      else {
+        const int jt = (j == 1) ? 1 : nyt;
+        en = 0.5 * (XF(nxt, jt) + XF(1, jt));
+      }
+    } else { // :194-202
+      const int it = (i == 1) ? 1 : nxt;
+      if (yin) en = 0.5 * (XF(it, j - 1) + XF(it, j));
+      else en = XF(it, (j == 1) ? 1 : nyt);
+    }
+#undef XF
+    P.entoc[(long)(j - 1) * P.ldx + (i - 1)] = en;
+    const double wx = (i == 1 || i == nx) ? 0.5 : 1.0, wy = (j == 1 || j == ny) ? 0.5 : 1.0; // xintp, src/intsubs.f:78-133
+    wsum = wx * wy * en;
+    if (j == 1) lsS = wx * en;  // src/omlsubs.F:222-231
+    if (j == ny) lsN = wx * en;
+  }
+  const int b = blockIdx.y * gridDim.x + blockIdx.x;
+  const double t0 = oml_block_sum(wsum, red, tid), t1 = oml_block_sum(lsS, red, tid), t2 = oml_block_sum(lsN, red, tid);
+  if (tid == 0) {
+    P.partB[b] = t0;
+    P.partB[P.nblkB + b] = t1;
+    P.partB[2 * P.nblkB + b] = t2;
+  }
+}
+
+__global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlParams P) {
+  __shared__ double red[OML_NT];
+  const int tid = threadIdx.x;
+  double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int k = tid; k < P.nblkB; k += OML_NT) {
+    a[0] += P.partB[k];
+    a[1] += P.partB[P.nblkB + k];
+    a[2] += P.partB[2 * P.nblkB + k];
+  }
+  for (int k = tid; k < P.nblkA; k += OML_NT) {
+    a[3] += P.partA[P.nblkA + k];
+    a[4] += P.partA[2 * P.nblkA + k];
+  }
+  double t[5];
+  for (int q = 0; q < 5; ++q) t[q] = oml_block_sum(a[q], red, tid);
+  if (tid == 0) {
+    P.sc->xon[0] = t[0] * P.dxo * P.dyo; // src/omlsubs.F:215-216
+    if (P.cyc) {
+      P.sc->enisoc[0] = P.dxo * t[1]; // :232-233
+      P.sc->eninoc[0] = P.dxo * t[2];
+    }
+    P.diag[0] = t[3] * P.ocnorm;        // cfraoc, :207
+    P.diag[1] = t[4] * P.dxo * P.dyo;   // centoc, :208
+  }
+}
+
+// leapfrog averaging of the mixed-layer temperature, src/q-gcm.F:1345-1351
+__global__ __launch_bounds__(256) void k_oml_average(double *sst, const double *sstm, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) sst[t] = 0.5 * (sst[t] + sstm[t]);
+}

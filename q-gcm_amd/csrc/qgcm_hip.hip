@@ -18,6 +18,7 @@
 #include "k_thomas.h"
 #include "k_misc.h"
 #include "k_cyclic.h"
+#include "k_oml.h"
 #include "slab_comm.h"
 
 static thread_local char g_err[512] = "";
@@ -34,9 +35,9 @@ static thread_local char g_err[512] = "";
     if (e_ != hipSuccess) QG_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_NOOP, KN_NOOP_TRAIN, KN_COUNT };
+enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_OML, KN_NOOP, KN_NOOP_TRAIN, KN_COUNT };
 static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_cyc_bsums", "k_dst_fwd", "k_thomas", "k_dst_inv",
-                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average", "k_noop", "k_noop_train"};
+                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average", "k_oml", "k_noop", "k_noop_train"};
 
 struct qgcm_hip_ctx {
   qgcm_hip_params prm;
@@ -78,6 +79,15 @@ struct qgcm_hip_ctx {
   int klaunch[KN_COUNT];
   // graphs keyed by (ip, iq, phase)
   std::map<int, hipGraphExec_t> graphs;
+  // ocean mixed layer (qgcm_hip_oml_init): three rotating sst buffers (is = sst, ism = sstm, spare = 3-is-ism)
+  struct {
+    bool on = false;
+    qgcm_hip_oml_params prm;
+    int ldt = 0, is = 0, ism = 1, nblkA = 0, nblkB = 0;
+    double *sst[3] = {nullptr, nullptr, nullptr};
+    double *fnet = nullptr, *wekto = nullptr, *xfo = nullptr, *taux = nullptr, *tauy = nullptr;
+    double *partA = nullptr, *partB = nullptr, *diag = nullptr;
+  } oml;
   // y-slab exchanges over RCCL (qgcm_hip_comm_init); slab-step graphs keyed like `graphs`
   QgSlabComm *sc_comm = nullptr;
   std::map<int, hipGraphExec_t> slab_graphs;
@@ -231,6 +241,10 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
       if (p) hipFree(p);
     delete m;
   }
+  double *omp[] = {c->oml.sst[0], c->oml.sst[1], c->oml.sst[2], c->oml.fnet, c->oml.wekto, c->oml.xfo,
+                   c->oml.taux, c->oml.tauy, c->oml.partA, c->oml.partB, c->oml.diag};
+  for (double *p : omp)
+    if (p) hipFree(p);
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
                     c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->ksum, c->wcot, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
@@ -961,11 +975,151 @@ extern "C" int qgcm_hip_lf_average(qgcm_hip_handle c) {
   return launch_lfavg(c);
 }
 
+// ---------------------------------------------------------------------------
+// ocean mixed layer
+// ---------------------------------------------------------------------------
+extern "C" int qgcm_hip_oml_init(qgcm_hip_handle c, const qgcm_hip_oml_params *p) {
+  if (check_ready(c, "qgcm_hip_oml_init")) return 1;
+  if (!p) QG_FAIL("qgcm_hip_oml_init: null parameters");
+  if (!c->whole) QG_FAIL("qgcm_hip_oml_init: the mixed layer is implemented for a handle that owns the whole domain");
+  if (!(p->hmoc > 0.0) || p->toc1 == p->toc2) QG_FAIL("qgcm_hip_oml_init: need hmoc > 0 and toc(1) != toc(2)");
+  const QgGeom &g = c->g;
+  const int nxt = g.nxt, nyt = g.ny - 1;
+  if (nxt < 3 || nyt < 3) QG_FAIL("qgcm_hip_oml_init: grid too small");
+  auto &o = c->oml;
+  o.prm = *p;
+  if (!o.sst[0]) {
+    o.ldt = round_up(nxt, 16);
+    const size_t nT = (size_t)o.ldt * nyt, nP = (size_t)g.ldx * g.ny;
+    o.nblkA = ((nxt + OML_TX - 1) / OML_TX) * ((nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+    o.nblkB = ((g.nx + OML_TX - 1) / OML_TX) * ((g.ny + OML_TY - 1) / OML_TY);
+    struct { double **ptr; size_t n; } bufs[] = {{&o.sst[0], nT}, {&o.sst[1], nT}, {&o.sst[2], nT}, {&o.fnet, nT}, {&o.wekto, nT},
+                                                 {&o.xfo, nT}, {&o.taux, nP}, {&o.tauy, nP}, {&o.partA, (size_t)3 * o.nblkA},
+                                                 {&o.partB, (size_t)3 * o.nblkB}, {&o.diag, 2}};
+    for (auto &b : bufs) {
+      HIPCHECK(hipMalloc((void **)b.ptr, b.n * sizeof(double)));
+      HIPCHECK(hipMemsetAsync(*b.ptr, 0, b.n * sizeof(double), c->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    o.is = 0;
+    o.ism = 1;
+  }
+  o.on = true;
+  return 0;
+}
+
+static int oml_ready(qgcm_hip_ctx *c, const char *who) {
+  if (check_ready(c, who)) return 1;
+  if (!c->oml.on) QG_FAIL("%s: qgcm_hip_oml_init has not been called", who);
+  return 0;
+}
+
+extern "C" int qgcm_hip_oml_set_state(qgcm_hip_handle c, const double *sst, const double *sstm) {
+  if (oml_ready(c, "qgcm_hip_oml_set_state")) return 1;
+  const int nxt = c->g.nxt, nyt = c->g.ny - 1;
+  if (sst && upload2d(c, c->oml.sst[c->oml.is], c->oml.ldt, sst, nxt, nyt)) return 1;
+  if (sstm && upload2d(c, c->oml.sst[c->oml.ism], c->oml.ldt, sstm, nxt, nyt)) return 1;
+  return 0;
+}
+
+extern "C" int qgcm_hip_oml_get_state(qgcm_hip_handle c, double *sst, double *sstm) {
+  if (oml_ready(c, "qgcm_hip_oml_get_state")) return 1;
+  const int nxt = c->g.nxt, nyt = c->g.ny - 1;
+  if (sst && download2d(c, sst, c->oml.sst[c->oml.is], c->oml.ldt, nxt, nyt)) return 1;
+  if (sstm && download2d(c, sstm, c->oml.sst[c->oml.ism], c->oml.ldt, nxt, nyt)) return 1;
+  return 0;
+}
+
+extern "C" int qgcm_hip_oml_set_forcing(qgcm_hip_handle c, const double *fnetoc, const double *wekto, const double *tauxo,
+                                        const double *tauyo) {
+  if (oml_ready(c, "qgcm_hip_oml_set_forcing")) return 1;
+  const QgGeom &g = c->g;
+  const int nxt = g.nxt, nyt = g.ny - 1;
+  if (fnetoc && upload2d(c, c->oml.fnet, c->oml.ldt, fnetoc, nxt, nyt)) return 1;
+  if (wekto && upload2d(c, c->oml.wekto, c->oml.ldt, wekto, nxt, nyt)) return 1;
+  if (tauxo && upload2d(c, c->oml.taux, g.ldx, tauxo, g.nx, g.ny)) return 1;
+  if (tauyo && upload2d(c, c->oml.tauy, g.ldx, tauyo, g.nx, g.ny)) return 1;
+  return 0;
+}
+
+static int launch_oml(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  const qgcm_hip_params &pr = c->prm;
+  auto &o = c->oml;
+  const qgcm_hip_oml_params &q = o.prm;
+  QgOmlParams P;
+  memset(&P, 0, sizeof(P));
+  P.nxt = g.nxt; P.nyt = g.ny - 1; P.nx = g.nx; P.ny = g.ny; P.cyc = g.cyc; P.sb = q.sb_hflux; P.nb = q.nb_hflux;
+  P.ldt = o.ldt; P.ldx = g.ldx;
+  const int spare = 3 - o.is - o.ism;
+  P.sst = o.sst[o.is]; P.sstm = o.sst[o.ism]; P.sstn = o.sst[spare];
+  P.fnet = o.fnet; P.wekto = o.wekto; P.xfo = o.xfo;
+  P.po1 = c->p[c->ip]; P.taux = o.taux; P.tauy = o.tauy;
+  P.entoc = c->entoc;
+  P.partA = o.partA; P.partB = o.partB; P.nblkA = o.nblkA; P.nblkB = o.nblkB;
+  P.sc = c->sc; P.diag = o.diag;
+  const double dxom2 = 1.0 / (pr.dxo * pr.dxo), rdxof0 = 1.0 / (pr.dxo * pr.fnot); // src/q-gcm.F:435
+  P.uvgfac = q.ycexp * rdxof0;           // src/omlsubs.F:274-277
+  P.rhf0hm = 0.5 / (pr.fnot * q.hmoc);
+  P.d2tfac = q.st2d * dxom2;
+  P.d4tfac = q.st4d * (dxom2 * dxom2);
+  P.hdxom1 = 0.5 / pr.dxo;
+  P.hmoinv = 1.0 / q.hmoc;               // src/omlsubs.F:78-80
+  P.dtoinv = 1.0 / (q.toc1 - q.toc2);
+  P.entfac = q.hmoc * P.dtoinv / pr.tdto;
+  P.tdto = pr.tdto; P.rrcpoc = q.rrcpoc; P.toc1 = q.toc1; P.tsbdy = q.tsbdy; P.tnbdy = q.tnbdy;
+  P.ocnorm = 1.0 / ((double)P.nxt * (double)P.nyt); // src/parameters_data.F:88
+  P.dxo = pr.dxo; P.dyo = pr.dyo;
+  KTimer t(c, KN_OML);
+  dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.ny + OML_TY - 1) / OML_TY);
+  hipLaunchKernelGGL(k_oml_step, gA, dim3(OML_NT), 0, c->stream, P);
+  hipLaunchKernelGGL(k_oml_entoc, gB, dim3(OML_NT), 0, c->stream, P);
+  hipLaunchKernelGGL(k_oml_final, dim3(1), dim3(OML_NT), 0, c->stream, P);
+  HIPCHECK(hipGetLastError());
+  // rotation: sstm <- sst, sst <- new (src/omlsubs.F:125-126)
+  o.ism = o.is;
+  o.is = spare;
+  return 0;
+}
+
+extern "C" int qgcm_hip_oml(qgcm_hip_handle c) {
+  if (oml_ready(c, "qgcm_hip_oml")) return 1;
+  return launch_oml(c);
+}
+
+static int launch_oml_average(qgcm_hip_ctx *c) {
+  const long n = (long)c->oml.ldt * (c->g.ny - 1);
+  hipLaunchKernelGGL(k_oml_average, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->oml.sst[c->oml.is],
+                     (const double *)c->oml.sst[c->oml.ism], n);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int qgcm_hip_oml_get_diag(qgcm_hip_handle c, double *entoc, double *diag) {
+  if (oml_ready(c, "qgcm_hip_oml_get_diag")) return 1;
+  const QgGeom &g = c->g;
+  if (entoc && download2d(c, entoc, c->entoc, g.ldx, g.nx, g.ny)) return 1;
+  if (diag) {
+    QgScalars h;
+    double d[2];
+    HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(d, c->oml.diag, sizeof(d), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    diag[0] = h.xon[0]; diag[1] = d[0]; diag[2] = d[1];
+    diag[3] = g.cyc ? h.enisoc[0] : 0.0; diag[4] = g.cyc ? h.eninoc[0] : 0.0;
+  }
+  return 0;
+}
+
 static int one_step(qgcm_hip_ctx *c, int s) {
+  if (c->oml.on && launch_oml(c)) return 1; // src/q-gcm.F:1232
   if (qgcm_hip_qgostep(c)) return 1;
   if (ocinvq_impl(c, true)) return 1; // ocqbdy fused into the unpack kernel
-  if ((s - 1) % 25 == 0)
+  if ((s - 1) % 25 == 0) {
     if (qgcm_hip_lf_average(c)) return 1;
+    if (c->oml.on && launch_oml_average(c)) return 1;
+  }
   if (c->profiling) {
     // an empty launch bracketed like the kernels (see qgcm_hip_profile_steps)
     KTimer t(c, KN_NOOP);
@@ -975,22 +1129,34 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   return 0;
 }
 
+// the sst buffers rotate with period 3 (sst -> sstm -> spare -> sst), one position per step
+static void oml_rotate(qgcm_hip_ctx *c, int nsteps) {
+  for (int r = 0; r < nsteps % 3; ++r) {
+    const int spare = 3 - c->oml.is - c->oml.ism;
+    c->oml.ism = c->oml.is;
+    c->oml.is = spare;
+  }
+}
+
 static int get_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   const int phase = (s0 - 1) % 25;
-  const int key = (c->ip << 16) | (c->iq << 8) | phase;
+  const int omk = c->oml.on ? 1 + 3 * c->oml.is + c->oml.ism : 0; // mixed layer on/off and its buffer rotation
+  const int key = (omk << 24) | (c->ip << 16) | (c->iq << 8) | phase;
   auto it = c->graphs.find(key);
   if (it != c->graphs.end()) {
     *out = it->second;
     return 0;
   }
   hipGraph_t graph;
-  const int ip0 = c->ip, iq0 = c->iq;
+  const int ip0 = c->ip, iq0 = c->iq, is0 = c->oml.is, ism0 = c->oml.ism;
   HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
   for (int s = s0; s < s0 + kGraphBlock && !rc; ++s) rc = one_step(c, s);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
   c->ip = ip0; // capture does not execute: restore the rotation state
   c->iq = iq0;
+  c->oml.is = is0;
+  c->oml.ism = ism0;
   if (rc) return 1;
   HIPCHECK(e);
   hipGraphExec_t exec;
@@ -1010,8 +1176,9 @@ extern "C" int qgcm_hip_steps(qgcm_hip_handle c, int s0, int n) {
     hipGraphExec_t ge;
     if (get_graph(c, s, &ge)) return 1;
     HIPCHECK(hipGraphLaunch(ge, c->stream));
-    s += kGraphBlock; // 50 steps: both rotations are back where they started
+    s += kGraphBlock; // 50 steps: the p and q rotations are back where they started, sst has moved on
     n -= kGraphBlock;
+    if (c->oml.on) oml_rotate(c, kGraphBlock);
   }
   for (; n > 0; --n, ++s)
     if (one_step(c, s)) return 1;

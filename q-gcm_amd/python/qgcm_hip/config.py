@@ -83,6 +83,36 @@ class OceanConfig:
         return steps_per_s * self.dto / 365.0
 
 
+@dataclass(frozen=True)
+class OmlConfig:
+    """Run-time parameters of the ocean mixed layer (oml / omladf, src/omlsubs.F): input.params entries
+    hmoc, st2d, st4d, ycexp, rhooc, cpoc (src/in_param.f), layer temperatures toc(1:2) (MODULE occonst) and
+    the reference's compile-time boundary options sb_hflux / nb_hflux with tsbdy / tnbdy (MODULE intrfac)."""
+    hmoc: float = 100.0
+    toc: Tuple[float, float] = (15.0, 10.0)
+    st2d: float = 100.0
+    st4d: float = 2.0e9
+    ycexp: float = 1.0
+    rhooc: float = 1.0e3
+    cpoc: float = 4.0e3
+    sb_hflux: bool = False
+    tsbdy: float = 0.0
+    nb_hflux: bool = False
+    tnbdy: float = 0.0
+
+    @property
+    def rrcpoc(self):  # src/q-gcm.F:438
+        return 1.0 / (self.rhooc * self.cpoc)
+
+
+def oml_preset(cfg, sb_hflux=False, nb_hflux=False):
+    """Mixed-layer parameters of the examples (input.params.dg_oo:46,66-70) with the diffusivities
+    scaled from the 5 km grid to cfg.dxo (same grid-scale damping rate)."""
+    r = cfg.dxo / 5.0e3
+    return OmlConfig(st2d=100.0 * r * r, st4d=2.0e9 * r ** 4, sb_hflux=sb_hflux, tsbdy=18.0 if sb_hflux else 0.0,
+                     nb_hflux=nb_hflux, tnbdy=12.0 if nb_hflux else 0.0)
+
+
 _NATL = dict(fnot=9.37456e-05, beta=1.75360e-11, cyclic=False)
 _SOCN = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True)
 

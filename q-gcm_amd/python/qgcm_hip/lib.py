@@ -30,6 +30,15 @@ class Params(C.Structure):
     ]
 
 
+class OmlParams(C.Structure):
+    """struct qgcm_hip_oml_params (include/qgcm_hip.h)."""
+    _fields_ = [
+        ("hmoc", C.c_double), ("toc1", C.c_double), ("toc2", C.c_double), ("st2d", C.c_double), ("st4d", C.c_double),
+        ("ycexp", C.c_double), ("rrcpoc", C.c_double), ("tsbdy", C.c_double), ("tnbdy", C.c_double),
+        ("sb_hflux", C.c_int), ("nb_hflux", C.c_int),
+    ]
+
+
 # every symbol include/qgcm_hip.h declares
 SYMBOLS = [
     "qgcm_hip_create", "qgcm_hip_destroy", "qgcm_hip_last_error", "qgcm_hip_abi_version",
@@ -42,6 +51,8 @@ SYMBOLS = [
     "qgcm_hip_constr", "qgcm_hip_unpack",
     "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack", "qgcm_hip_slab_stage",
     "qgcm_hip_comm_unique_id", "qgcm_hip_comm_init", "qgcm_hip_slab_steps",
+    "qgcm_hip_oml_init", "qgcm_hip_oml_set_state", "qgcm_hip_oml_get_state", "qgcm_hip_oml_set_forcing",
+    "qgcm_hip_oml", "qgcm_hip_oml_get_diag",
     "qgcm_hip_time_steps", "qgcm_hip_profile_steps", "qgcm_hip_copy_bandwidth", "qgcm_hip_stream",
 ]
 
@@ -91,6 +102,12 @@ def load_library():
     L.qgcm_hip_comm_unique_id.argtypes = [C.c_char_p, C.c_int]
     L.qgcm_hip_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int]
     L.qgcm_hip_slab_steps.argtypes = [vp, C.c_int, C.c_int]
+    L.qgcm_hip_oml_init.argtypes = [vp, C.POINTER(OmlParams)]
+    L.qgcm_hip_oml_set_state.argtypes = [vp, dp, dp]
+    L.qgcm_hip_oml_get_state.argtypes = [vp, dp, dp]
+    L.qgcm_hip_oml_set_forcing.argtypes = [vp, dp, dp, dp, dp]
+    L.qgcm_hip_oml.argtypes = [vp]
+    L.qgcm_hip_oml_get_diag.argtypes = [vp, dp, dp]
     L.qgcm_hip_time_steps.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.qgcm_hip_profile_steps.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_int),
                                          C.POINTER(C.c_char_p), C.POINTER(C.c_int)]

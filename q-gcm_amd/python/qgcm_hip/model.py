@@ -177,6 +177,42 @@ class OceanModel:
     def sync(self):
         check(self.L.qgcm_hip_sync(self.h))
 
+    # -- ocean mixed layer (`call oml`, src/q-gcm.F:1232) -------
+    def oml_init(self, om):
+        """Switch the mixed layer on (om: qgcm_hip.config.OmlConfig): steps() then runs oml before
+        qgostep in every step and averages sst with the other fields."""
+        from .lib import OmlParams
+        p = OmlParams()
+        p.hmoc, p.toc1, p.toc2, p.st2d, p.st4d = om.hmoc, om.toc[0], om.toc[1], om.st2d, om.st4d
+        p.ycexp, p.rrcpoc, p.tsbdy, p.tnbdy = om.ycexp, om.rrcpoc, om.tsbdy, om.tnbdy
+        p.sb_hflux, p.nb_hflux = int(om.sb_hflux), int(om.nb_hflux)
+        check(self.L.qgcm_hip_oml_init(self.h, C.byref(p)))
+
+    def oml_set_state(self, sst=None, sstm=None):
+        a = [_f(x) for x in (sst, sstm)]
+        for x in a:
+            assert x is None or x.shape == (self.cfg.nxto, self.cfg.nyto)
+        check(self.L.qgcm_hip_oml_set_state(self.h, *[_dp(x) for x in a]))
+
+    def oml_get_state(self):
+        a = [np.zeros((self.cfg.nxto, self.cfg.nyto), order="F") for _ in range(2)]
+        check(self.L.qgcm_hip_oml_get_state(self.h, *[_dp(x) for x in a]))
+        return a
+
+    def oml_set_forcing(self, fnetoc=None, wekto=None, tauxo=None, tauyo=None):
+        a = [_f(x) for x in (fnetoc, wekto, tauxo, tauyo)]
+        check(self.L.qgcm_hip_oml_set_forcing(self.h, *[_dp(x) for x in a]))
+
+    def oml(self):
+        check(self.L.qgcm_hip_oml(self.h))
+
+    def oml_get_diag(self):
+        """entoc(nxpo,nypo) and (xon(1), cfraoc, centoc, enisoc(1), eninoc(1))."""
+        e = np.zeros((self.cfg.nxpo, self.cfg.nypo), order="F")
+        d = np.zeros(5)
+        check(self.L.qgcm_hip_oml_get_diag(self.h, _dp(e), _dp(d)))
+        return e, d
+
     def helmholtz(self, wrk, boc):
         """hsbxoc / hscyoc replacement (src/ocisubs.F:415-618); returns the solution."""
         w = np.array(wrk, dtype=np.float64, order="F", copy=True)

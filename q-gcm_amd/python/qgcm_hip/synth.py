@@ -78,3 +78,24 @@ def gaussian_eddy(cfg, amp=0.15, lfold=None, xc=0.4, yc=0.55, noise=0.0, seed=24
         if cfg.cyclic:
             po[-1, :, :] = po[0, :, :]
     return po
+
+
+def mixed_layer_fields(cfg, oml, seed=None):
+    """Deterministic synthetic inputs of the ocean mixed layer: sst, sstm, fnetoc on the
+    T grid (nxto,nyto) and a wind stress with both components on the p grid.  sst straddles toc(1) so that
+    the convective adjustment of eqn (7.13) (src/omlsubs.F:116-119) is active in the northern half."""
+    nxt, nyt = cfg.nxto, cfg.nyto
+    x = (np.arange(nxt)[:, None] + 0.5) / nxt
+    y = (np.arange(nyt)[None, :] + 0.5) / nyt
+    sst = oml.toc[0] + 2.0 * np.cos(np.pi * y) + 0.5 * np.sin(2.0 * np.pi * x) * np.sin(np.pi * y)
+    sstm = sst - 0.05 * np.cos(2.0 * np.pi * x) * np.cos(np.pi * y)
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+        sst = sst + 0.05 * rng.uniform(-1.0, 1.0, sst.shape)
+        sstm = sstm + 0.05 * rng.uniform(-1.0, 1.0, sst.shape)
+    fnet = 40.0 * np.cos(np.pi * y) * (1.0 + 0.2 * np.sin(2.0 * np.pi * x))
+    tx, ty = wind_stress(cfg)
+    xp = np.arange(cfg.nxpo)[:, None] / (cfg.nxpo - 1.0)
+    yp = np.arange(cfg.nypo)[None, :] / (cfg.nypo - 1.0)
+    ty = np.asfortranarray(2.0e-5 * np.sin(2.0 * np.pi * xp) * np.sin(np.pi * yp))
+    return (np.asfortranarray(sst), np.asfortranarray(sstm), np.asfortranarray(fnet), np.asfortranarray(tx), ty)

@@ -65,3 +65,29 @@ SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_small": (1, 
 
 def preset(name):
     return config.preset(name)
+
+
+# ---- ocean mixed layer fixtures (tests/golden/make_golden_oml.py) -----------------------------
+OML_CASES = (("oml_box_tiny", "box_tiny"), ("oml_box_tiny_sb", "box_tiny"), ("oml_cyc_tiny", "cyc_tiny"))
+OML_SNAPS = (1, 2, 26, 40)
+
+
+def oml_config(g):
+    """OmlConfig of a mixed-layer fixture."""
+    p = g["oml_params"]
+    return config.OmlConfig(hmoc=p[0], toc=(p[1], p[2]), st2d=p[3], st4d=p[4], ycexp=p[5], rhooc=1.0, cpoc=1.0 / p[6],
+                            sb_hflux=bool(p[7]), tsbdy=p[8], nb_hflux=bool(p[9]), tnbdy=p[10])
+
+
+def oml_load(model, g, cfg, is_oracle):
+    """Inputs of a mixed-layer fixture into an Oracle or an OceanModel."""
+    nl = cfg.nlo
+    model.set_p(g["in_po"], g["in_pom"])
+    model.set_forcing(g["in_wekpo"], np.zeros((cfg.nxpo, cfg.nypo), order="F"), np.zeros(nl - 1))
+    if cfg.cyclic:
+        model.set_cyc_forcing(float(g["in_txis"]), float(g["in_txin"]), np.zeros(nl - 1), np.zeros(nl - 1))
+    if is_oracle:
+        model.oml_set(g["in_sst"], g["in_sstm"], g["in_fnetoc"], g["in_wekto"], g["in_tauxo"], g["in_tauyo"])
+    else:
+        model.oml_set_state(g["in_sst"], g["in_sstm"])
+        model.oml_set_forcing(g["in_fnetoc"], g["in_wekto"], g["in_tauxo"], g["in_tauyo"])
