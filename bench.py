@@ -345,6 +345,26 @@ def main():
                                               "subtracted": round(bracket_us, 3)},
                          "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 3) for k, v in prof.items()}},
         }
+        # Secondary figure (not `value`): the same workload with the ocean mixed layer on the device
+        # (`call oml`) - the end-to-end ocean-only step without any per-step PCIe traffic.
+        try:
+            from qgcm_hip import oml_preset, synth
+            om = oml_preset(cfg)
+            sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om)
+            wekto, _ = synth.wekpo_from_tau(cfg, tx, ty)
+            model.oml_init(om)
+            model.oml_set_state(sst, sstm)
+            model.oml_set_forcing(fnet, wekto, tx, ty)
+            model.set_p(po, po)
+            model.steps(300, s0=1)  # warm-up: the three 50-step graphs of the sst buffer rotation get instantiated
+            ms = model.time_steps(args.steps, s0=301)
+            pr2 = model.profile_steps(50, s0=301 + args.steps)
+            st_ok = bool(np.isfinite(model.oml_get_state()[0]).all())
+            out["with_mixed_layer"] = {"steps_per_s": round(args.steps / (ms * 1e-3), 2),
+                                       "ms_per_step": round(ms / args.steps, 5), "state_finite": st_ok,
+                                       "oml_kernels_us_eager_bracket": round(1e3 * pr2["k_oml"][0] / max(pr2["k_oml"][1], 1), 3)}
+        except Exception as e:  # noqa: BLE001 - secondary figure only
+            out["with_mixed_layer"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             model.close()
             out["cpu_baseline"] = cpu_baseline(cfg, po, wek)

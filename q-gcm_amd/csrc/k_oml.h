@@ -87,24 +87,38 @@ __device__ __forceinline__ double oml_del2t_x(const QgOmlParams &P, int i, int j
   return oml_del2t(P, i, j);
 }
 
-__device__ inline double oml_block_sum(double v, double *red, int tid) {
-  red[tid] = v;
-  __syncthreads();
-  for (int off = OML_NT / 2; off > 0; off >>= 1) {
-    if (tid < off) red[tid] += red[tid + off];
-    __syncthreads();
+// Sums of NV values over the 256 threads of a workgroup in a fixed order (xor butterfly inside each wave, then the
+// four wave totals left to right); every thread returns with the totals. One barrier; sm is (NV x 4) doubles.
+template <int NV>
+__device__ __forceinline__ void oml_block_sums(double *v, double *sm, int tid) {
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off);
+    if ((tid & 63) == 0) sm[q * 4 + (tid >> 6)] = v[q];
   }
-  double r = red[0];
   __syncthreads();
-  return r;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = (sm[q * 4] + sm[q * 4 + 1]) + (sm[q * 4 + 2] + sm[q * 4 + 3]);
 }
 
 // grid: (ceil(nxt/64), ceil(nyt/16)), block 256 = 64 x 4; thread rows j0 + ty + 4 r
 __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
-  __shared__ double red[OML_NT];
+  constexpr int TH = OML_TY * OML_RPT;      // tile rows
+  constexpr int DW = OML_TX + 2, DH = TH + 2; // del2t tile with a halo of one
+  __shared__ double sD[DH * DW];
+  __shared__ double red[12];
   const int tid = threadIdx.x;
-  const int i = blockIdx.x * OML_TX + (tid % OML_TX) + 1;
+  const int i0 = blockIdx.x * OML_TX + 1, j0 = blockIdx.y * TH + 1;
+  const int lx0 = tid % OML_TX, ly0 = tid / OML_TX;
+  const int i = i0 + lx0;
   const int nxt = P.nxt, nyt = P.nyt;
+  // del2t of the tile and its halo, each value once (dummy columns by the wall / wrap rule)
+  for (int idx = tid; idx < DH * DW; idx += OML_NT) {
+    const int gi = i0 - 1 + idx % DW, gj = j0 - 1 + idx / DW;
+    sD[idx] = (gj >= 1 && gj <= nyt && gi >= 0 && gi <= nxt + 1) ? oml_del2t_x(P, gi, gj) : 0.0;
+  }
+  __syncthreads();
   const long ldt = P.ldt, ldx = P.ldx;
   const double uvgfac = P.uvgfac, rhf0hm = P.rhf0hm, hdxom1 = P.hdxom1;
   double sxfo = 0.0, scfr = 0.0, scen = 0.0;
@@ -116,7 +130,8 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
 #define VF(ii, jj) (uvgfac * (PO1((ii) + 1, jj) - PO1(ii, jj)) - rhf0hm * (TXo((ii) + 1, jj) + TXo(ii, jj)))
 #pragma unroll
   for (int r = 0; r < OML_RPT; ++r) {
-    const int j = blockIdx.y * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + 1;
+    const int ly = ly0 + OML_TY * r;
+    const int j = j0 + ly;
     if (i > nxt || j > nyt) continue;
     // ---- advection, src/omlsubs.F:281-346 (rows), 370-456 (S/N rows), 458-700 (corners) ----
     double um, tm, up, tp;
@@ -144,10 +159,11 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
     }
     double rhs = -(hxadv + hyadv);
     // ---- diffusion, src/omlsubs.F:733-759 ----
-    const double dc = oml_del2t(P, i, j), dw = oml_del2t_x(P, i - 1, j), de = oml_del2t_x(P, i + 1, j);
-    if (j == 1) rhs = rhs + P.d2tfac * dc - P.d4tfac * (dw + de + oml_del2t(P, i, 2) - 3.0 * dc);
-    else if (j == nyt) rhs = rhs + P.d2tfac * dc - P.d4tfac * (oml_del2t(P, i, nyt - 1) + dw + de - 3.0 * dc);
-    else rhs = rhs + P.d2tfac * dc - P.d4tfac * (oml_del2t(P, i, j - 1) + dw + de + oml_del2t(P, i, j + 1) - 4.0 * dc);
+    const double *d = &sD[(ly + 1) * DW + (lx0 + 1)];
+    const double dc = d[0], dw = d[-1], de = d[1];
+    if (j == 1) rhs = rhs + P.d2tfac * dc - P.d4tfac * (dw + de + d[DW] - 3.0 * dc);
+    else if (j == nyt) rhs = rhs + P.d2tfac * dc - P.d4tfac * (d[-DW] + dw + de - 3.0 * dc);
+    else rhs = rhs + P.d2tfac * dc - P.d4tfac * (d[-DW] + dw + de + d[DW] - 4.0 * dc);
     // ---- oml, src/omlsubs.F:101-128 ----
     const long o = (long)(j - 1) * ldt + (i - 1);
     const double sm = P.sstm[o], wk = P.wekto[o];
@@ -171,28 +187,32 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
 #undef UF
 #undef VF
   const int b = blockIdx.y * gridDim.x + blockIdx.x;
-  const double t0 = oml_block_sum(sxfo, red, tid), t1 = oml_block_sum(scfr, red, tid), t2 = oml_block_sum(scen, red, tid);
+  double t[3] = {sxfo, scfr, scen};
+  oml_block_sums<3>(t, red, tid);
   if (tid == 0) {
-    P.partA[b] = t0;
-    P.partA[P.nblkA + b] = t1;
-    P.partA[2 * P.nblkA + b] = t2;
+    P.partA[b] = t[0];
+    P.partA[P.nblkA + b] = t[1];
+    P.partA[2 * P.nblkA + b] = t[2];
   }
 }
 
-// grid: (ceil(nx/64), ceil(ny/4)), block 256 = 64 x 4, one p point per thread
+// grid: (ceil(nx/64), ceil(ny/16)), block 256 = 64 x 4, thread rows j0 + ty + 4 r
 __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
-  __shared__ double red[OML_NT];
+  __shared__ double redm[4], red[12];
   const int tid = threadIdx.x;
   // mean entrainment: the same fixed-order reduction of the partials in every workgroup
-  double s = 0.0;
-  for (int k = tid; k < P.nblkA; k += OML_NT) s += P.partA[k];
-  const double xmean = oml_block_sum(s, red, tid) * P.ocnorm; // xfosum*ocnorm, src/omlsubs.F:153
+  double s[1] = {0.0};
+  for (int k = tid; k < P.nblkA; k += OML_NT) s[0] += P.partA[k];
+  oml_block_sums<1>(s, redm, tid);
+  const double xmean = s[0] * P.ocnorm; // xfosum*ocnorm, src/omlsubs.F:153
   const int i = blockIdx.x * OML_TX + (tid % OML_TX) + 1;
-  const int j = blockIdx.y * OML_TY + (tid / OML_TX) + 1;
   const int nx = P.nx, ny = P.ny, nxt = P.nxt, nyt = P.nyt;
   const long ldt = P.ldt;
-  double wsum = 0.0, lsS = 0.0, lsN = 0.0;
-  if (i <= nx && j <= ny) {
+  double t[3] = {0.0, 0.0, 0.0}; // xintp sum, S and N line sums
+#pragma unroll
+  for (int r = 0; r < OML_RPT; ++r) {
+    const int j = blockIdx.y * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + 1;
+    if (i > nx || j > ny) continue;
 #define XF(ii, jj) (P.xfo[(long)((jj)-1) * ldt + ((ii)-1)] - xmean)
     double en;
     const bool xin = (i >= 2 && i <= nx - 1), yin = (j >= 2 && j <= ny - 1);
@@ -214,21 +234,21 @@ __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
 #undef XF
     P.entoc[(long)(j - 1) * P.ldx + (i - 1)] = en;
     const double wx = (i == 1 || i == nx) ? 0.5 : 1.0, wy = (j == 1 || j == ny) ? 0.5 : 1.0; // xintp, src/intsubs.f:78-133
-    wsum = wx * wy * en;
-    if (j == 1) lsS = wx * en;  // src/omlsubs.F:222-231
-    if (j == ny) lsN = wx * en;
+    t[0] += wx * wy * en;
+    if (j == 1) t[1] += wx * en;  // src/omlsubs.F:222-231
+    if (j == ny) t[2] += wx * en;
   }
   const int b = blockIdx.y * gridDim.x + blockIdx.x;
-  const double t0 = oml_block_sum(wsum, red, tid), t1 = oml_block_sum(lsS, red, tid), t2 = oml_block_sum(lsN, red, tid);
+  oml_block_sums<3>(t, red, tid);
   if (tid == 0) {
-    P.partB[b] = t0;
-    P.partB[P.nblkB + b] = t1;
-    P.partB[2 * P.nblkB + b] = t2;
+    P.partB[b] = t[0];
+    P.partB[P.nblkB + b] = t[1];
+    P.partB[2 * P.nblkB + b] = t[2];
   }
 }
 
 __global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlParams P) {
-  __shared__ double red[OML_NT];
+  __shared__ double red[20];
   const int tid = threadIdx.x;
   double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int k = tid; k < P.nblkB; k += OML_NT) {
@@ -240,8 +260,8 @@ __global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlParams P) {
     a[3] += P.partA[P.nblkA + k];
     a[4] += P.partA[2 * P.nblkA + k];
   }
-  double t[5];
-  for (int q = 0; q < 5; ++q) t[q] = oml_block_sum(a[q], red, tid);
+  double *t = a;
+  oml_block_sums<5>(a, red, tid);
   if (tid == 0) {
     P.sc->xon[0] = t[0] * P.dxo * P.dyo; // src/omlsubs.F:215-216
     if (P.cyc) {

@@ -992,7 +992,7 @@ extern "C" int qgcm_hip_oml_init(qgcm_hip_handle c, const qgcm_hip_oml_params *p
     o.ldt = round_up(nxt, 16);
     const size_t nT = (size_t)o.ldt * nyt, nP = (size_t)g.ldx * g.ny;
     o.nblkA = ((nxt + OML_TX - 1) / OML_TX) * ((nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
-    o.nblkB = ((g.nx + OML_TX - 1) / OML_TX) * ((g.ny + OML_TY - 1) / OML_TY);
+    o.nblkB = ((g.nx + OML_TX - 1) / OML_TX) * ((g.ny + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
     struct { double **ptr; size_t n; } bufs[] = {{&o.sst[0], nT}, {&o.sst[1], nT}, {&o.sst[2], nT}, {&o.fnet, nT}, {&o.wekto, nT},
                                                  {&o.xfo, nT}, {&o.taux, nP}, {&o.tauy, nP}, {&o.partA, (size_t)3 * o.nblkA},
                                                  {&o.partB, (size_t)3 * o.nblkB}, {&o.diag, 2}};
@@ -1072,7 +1072,7 @@ static int launch_oml(qgcm_hip_ctx *c) {
   P.dxo = pr.dxo; P.dyo = pr.dyo;
   KTimer t(c, KN_OML);
   dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
-  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.ny + OML_TY - 1) / OML_TY);
+  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.ny + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
   hipLaunchKernelGGL(k_oml_step, gA, dim3(OML_NT), 0, c->stream, P);
   hipLaunchKernelGGL(k_oml_entoc, gB, dim3(OML_NT), 0, c->stream, P);
   hipLaunchKernelGGL(k_oml_final, dim3(1), dim3(OML_NT), 0, c->stream, P);

@@ -20,7 +20,8 @@ module occonst
   implicit none
   public
   save
-  double precision :: dxo, dyo, dxom2, xlo, ylo, delek, dto, tdto, bccooc
+  double precision :: dxo, dyo, dxom2, xlo, ylo, delek, dto, tdto, bccooc, ycexp
+  double precision, allocatable :: toc(:)
   double precision, allocatable :: yporel(:), gpoc(:), hoc(:), ah2oc(:), ah4oc(:), &
                                    amatoc(:,:), rdm2oc(:), ctl2moc(:,:), ctm2loc(:,:), ddynoc(:,:)
 end module occonst
@@ -42,5 +43,21 @@ module ocstate
   implicit none
   public
   save
-  double precision, allocatable :: po(:,:,:), pom(:,:,:), qo(:,:,:), qom(:,:,:), entoc(:,:), wekpo(:,:)
+  double precision, allocatable :: po(:,:,:), pom(:,:,:), qo(:,:,:), qom(:,:,:), entoc(:,:), wekpo(:,:), wekto(:,:)
 end module ocstate
+
+! what the mixed-layer shim (MODULE omlsubs) reads of src/intrfac_data.F and src/radiate_data.F
+module intrfac
+  implicit none
+  public
+  save
+  double precision, allocatable :: sst(:,:), sstm(:,:), fnetoc(:,:), tauxo(:,:), tauyo(:,:)
+  double precision :: hmoc, st2d, st4d, tsbdy, tnbdy
+end module intrfac
+
+module radiate
+  implicit none
+  public
+  save
+  double precision :: rrcpoc
+end module radiate

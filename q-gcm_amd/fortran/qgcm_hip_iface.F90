@@ -24,6 +24,12 @@ module qgcm_hip_iface
     integer(c_int) :: slab_g0, slab_g1
   end type qgcm_hip_params
 
+  ! struct qgcm_hip_oml_params: run-time parameters of the ocean mixed layer
+  type, bind(C) :: qgcm_hip_oml_params
+    real(c_double) :: hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, tsbdy, tnbdy
+    integer(c_int) :: sb_hflux, nb_hflux
+  end type qgcm_hip_oml_params
+
   interface
     integer(c_int) function qgcm_hip_create(h, prm, device) bind(C, name='qgcm_hip_create')
       import :: c_ptr, c_int, qgcm_hip_params
@@ -116,6 +122,36 @@ module qgcm_hip_iface
       type(c_ptr), value :: h
       real(c_double), intent(inout) :: wrk(*)
       real(c_double), intent(in) :: boc(*)
+    end function
+    ! ocean mixed layer: "call oml" (src/q-gcm.F:1232) on the device
+    integer(c_int) function qgcm_hip_oml_init(h, prm) bind(C, name='qgcm_hip_oml_init')
+      import :: c_ptr, c_int, qgcm_hip_oml_params
+      type(c_ptr), value :: h
+      type(qgcm_hip_oml_params), intent(in) :: prm
+    end function
+    integer(c_int) function qgcm_hip_oml_set_state(h, sst, sstm) bind(C, name='qgcm_hip_oml_set_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: sst(*), sstm(*)
+    end function
+    integer(c_int) function qgcm_hip_oml_get_state(h, sst, sstm) bind(C, name='qgcm_hip_oml_get_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: sst(*), sstm(*)
+    end function
+    integer(c_int) function qgcm_hip_oml_set_forcing(h, fnetoc, wekto, tauxo, tauyo) bind(C, name='qgcm_hip_oml_set_forcing')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: fnetoc(*), wekto(*), tauxo(*), tauyo(*)
+    end function
+    integer(c_int) function qgcm_hip_oml(h) bind(C, name='qgcm_hip_oml')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_oml_get_diag(h, entoc, diag) bind(C, name='qgcm_hip_oml_get_diag')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: entoc(*), diag(5)
     end function
     ! y-slab runs, one process per GPU: rendezvous id (rank 0), communicator, whole distributed steps
     ! (the library issues the RCCL exchanges itself; include/qgcm_hip.h)

@@ -224,3 +224,71 @@ contains
     call qgcm_hip_check(qgcm_hip_ocqbdy(qgcm_hip_handle), 'ocqbdy')
   end subroutine ocqbdy
 end module vorsubs_hip
+
+
+!-----------------------------------------------------------------------
+! MODULE omlsubs: drop-in for `call oml` (src/q-gcm.F:1232, body src/omlsubs.F:47-236 + omladf 244-763;
+! SURVEY 8 row f1).  The mixed layer runs on the device next to the PV path: entoc, xon(1) and (cyclic)
+! enisoc(1)/eninoc(1) never leave the GPU, so the per-step PCIe traffic of a host-side oml
+! (po(:,:,1) down, entoc up: 2 x 7.4 MB at 5 km) disappears.
+!   call qgcm_hip_oml_push        once after the initial sst / forcing are set (and after a restart read;
+!                                 again whenever xforc changes fnetoc / wekto / tauxo / tauyo)
+!   call oml                      every ocean step, before qgostep (unchanged call site)
+!   call qgcm_hip_oml_pull        before anything on the host reads sst / sstm / entoc / xon
+! Build with the reference's cpp macros (sb_hflux / nb_hflux select the boundary variants there; here they
+! become the run-time flags of qgcm_hip_oml_params).
+!-----------------------------------------------------------------------
+module omlsubs
+  use iso_c_binding
+  use qgcm_hip_iface
+  use qgcm_hip_state
+  implicit none
+  private
+  public :: oml, qgcm_hip_oml_push, qgcm_hip_oml_pull
+  logical, save :: oml_ready = .false.
+contains
+
+  subroutine qgcm_hip_oml_push
+    use occonst, only : toc, ycexp
+    use ocstate, only : wekto
+    use intrfac, only : sst, sstm, fnetoc, tauxo, tauyo, hmoc, st2d, st4d, tsbdy, tnbdy
+    use radiate, only : rrcpoc
+    type(qgcm_hip_oml_params) :: p
+    call qgcm_hip_ensure
+    if (.not. oml_ready) then
+      p%hmoc = hmoc; p%toc1 = toc(1); p%toc2 = toc(2); p%st2d = st2d; p%st4d = st4d
+      p%ycexp = ycexp; p%rrcpoc = rrcpoc; p%tsbdy = tsbdy; p%tnbdy = tnbdy
+      p%sb_hflux = 0; p%nb_hflux = 0
+#ifdef sb_hflux
+      p%sb_hflux = 1
+#endif
+#ifdef nb_hflux
+      p%nb_hflux = 1
+#endif
+      call qgcm_hip_check(qgcm_hip_oml_init(qgcm_hip_handle, p), 'qgcm_hip_oml_init')
+      oml_ready = .true.
+    endif
+    call qgcm_hip_check(qgcm_hip_oml_set_state(qgcm_hip_handle, sst, sstm), 'qgcm_hip_oml_set_state')
+    call qgcm_hip_check(qgcm_hip_oml_set_forcing(qgcm_hip_handle, fnetoc, wekto, tauxo, tauyo), 'qgcm_hip_oml_set_forcing')
+  end subroutine qgcm_hip_oml_push
+
+  subroutine oml
+    if (.not. oml_ready) call qgcm_hip_oml_push
+    call qgcm_hip_check(qgcm_hip_oml(qgcm_hip_handle), 'qgcm_hip_oml')
+  end subroutine oml
+
+  subroutine qgcm_hip_oml_pull
+    use ocstate, only : entoc
+    use ochomog
+    use intrfac, only : sst, sstm
+    real(c_double) :: diag(5)
+    call qgcm_hip_check(qgcm_hip_oml_get_state(qgcm_hip_handle, sst, sstm), 'qgcm_hip_oml_get_state')
+    call qgcm_hip_check(qgcm_hip_oml_get_diag(qgcm_hip_handle, entoc, diag), 'qgcm_hip_oml_get_diag')
+    xon(1) = diag(1)
+#ifdef cyclic_ocean
+    enisoc(1) = diag(4)
+    eninoc(1) = diag(5)
+#endif
+  end subroutine qgcm_hip_oml_pull
+
+end module omlsubs

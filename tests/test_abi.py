@@ -36,6 +36,15 @@ def test_params_struct_layout():
     assert ctypes.sizeof(lib.Params) == 4 * 4 + 8 * (7 + 4 * n + 3 * n * n + n + 1) + 2 * 4
 
 
+def test_oml_params_struct_layout(repo_root):
+    # 9 doubles + 2 ints, field order as in include/qgcm_hip.h
+    assert ctypes.sizeof(lib.OmlParams) == 9 * 8 + 2 * 4
+    hdr = open(os.path.join(repo_root, "include", "qgcm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct qgcm_hip_oml_params {"):hdr.index("} qgcm_hip_oml_params;")]
+    pos = [body.index(" %s" % f[0]) for f in lib.OmlParams._fields_]
+    assert pos == sorted(pos)
+
+
 def test_create_fails_loudly_without_gpu():
     """No CPU fallback: on a box without a HIP device the constructor raises."""
     import torch
