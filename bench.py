@@ -135,8 +135,8 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     """N > 1: y-slab decomposition, one rank per GPU over RCCL (weak scaling).
 
     Every rank owns a NAtl-5km-shaped slab (961 x ~960 rows x 3 layers) of a basin that
-    is `world` times taller (961 x (960*world+1)); the ranks exchange Thomas slab maps,
-    area-integral partials and halo rows every step (qgcm_hip.slab.SlabOcean).  The
+    is `world` times taller (961 x (960*world+1)); the ranks exchange slab summaries (tridiagonal
+    sweeps + area integrals) and halo rows every step (qgcm_hip_slab_steps / qgcm_hip.slab.SlabOcean).  The
     reported value counts NAtl-5km-equivalent timesteps: world x (basin steps / s)."""
     import dataclasses
 
@@ -215,8 +215,8 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             "config": {"workload": "NAtl 5km-shaped slab per GPU: 961 x %d x 3 basin (%d x taller), dto=540s, "
                                    "Gaussian-eddy IC + double-gyre wind, oml off" % (cfg.nypo, world),
                        "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
-                       "parallelism": "y-slabs over %d GPUs: per step one all-gather each of the Thomas slab summaries, "
-                                      "the area-integral partials and the halo rows (RCCL)" % world,
+                       "parallelism": "y-slabs over %d GPUs: two exchanges per step - one all-gather of the slab summaries "
+                                      "(tridiagonal sweeps + area integrals) and one of the halo rows (RCCL)" % world,
                        "exchange_driver": driver,
                        "value_counts": "NAtl-5km-equivalent timesteps = n_gpus x basin timesteps"},
             "basin_steps_per_s": round(basin_sps, 2),
