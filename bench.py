@@ -187,6 +187,31 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if t.item() > 0.5:
             driver = "library-issued RCCL (qgcm_hip_slab_steps), verified bitwise against the torch.distributed driver"
+            # transport of the halo rows: one all-gather of everybody's edge rows, or grouped send/recv with the
+            # two neighbours - measured on this node (max over ranks), the faster one is used if it is also bitwise
+            def timed(p2p):
+                slab.set_halo_p2p(p2p)
+                so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
+                so.steps(nver, s0=1)
+                same = all(np.array_equal(a, b) for a, b in zip(ref, local_state()))
+                so.steps(50, s0=nver + 1)
+                barrier()
+                t0 = time.perf_counter()
+                so.steps(100, s0=nver + 51)
+                barrier()
+                tt = torch.tensor([time.perf_counter() - t0, 0.0 if same else 1.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt[0].item()), tt[1].item() < 0.5
+            try:
+                t_ag, ok_ag = timed(False)
+                t_pp, ok_pp = timed(True)
+                use_p2p = ok_pp and (t_pp < t_ag or not ok_ag)
+                slab.set_halo_p2p(use_p2p)
+                driver += "; halo rows by %s (all-gather %.1f us/step, send/recv %.1f us/step%s)" % (
+                    "send/recv" if use_p2p else "all-gather", 1e4 * t_ag, 1e4 * t_pp, "" if ok_pp else ", send/recv NOT bitwise")
+            except Exception as e:  # noqa: BLE001
+                print("halo transport tuning failed: %r" % (e,), file=sys.stderr)
+                slab.set_halo_p2p(False)
         else:
             so.native = False
     so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)

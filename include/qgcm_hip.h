@@ -181,6 +181,9 @@ int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_d
 int qgcm_hip_comm_unique_id(char *id, int nbytes);
 int qgcm_hip_comm_init(qgcm_hip_handle h, const char *id, int nbytes, int rank, int nranks);
 int qgcm_hip_slab_steps(qgcm_hip_handle h, int s0, int n);
+/* edge rows as grouped send/recv with the two neighbours (1) or as one all-gather (0); collective:
+ * every rank must make the same choice */
+int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle h, int on);
 
 /* ---- ocean mixed layer -----------------------------------
  * `call oml` (src/q-gcm.F:1232; body src/omlsubs.F:47-236 + omladf 244-763) on the device: steps the

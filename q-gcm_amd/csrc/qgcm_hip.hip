@@ -1377,6 +1377,17 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   return 0;
 }
 
+extern "C" int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle c, int on) {
+  if (!c || !c->sc_comm) QG_FAIL("qgcm_hip_comm_set_halo_p2p: no communicator (qgcm_hip_comm_init)");
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (c->sc_comm->halo_p2p != (on != 0)) {
+    for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second); // captured steps contain the old exchange
+    c->slab_graphs.clear();
+  }
+  c->sc_comm->halo_p2p = (on != 0);
+  return 0;
+}
+
 // one distributed ocean step: three communication-free stages (the same calls SlabOcean.step makes through
 // qgcm_hip_slab_stage) and two exchanges, all ordered on c->stream; no host synchronisation
 static int slab_step(qgcm_hip_ctx *c, int s) {

@@ -271,6 +271,9 @@ class HipSlab:
         check(self.L.qgcm_hip_comm_init(self.h, comm_id, len(comm_id), self.rank, self.nranks))
         self.has_comm = True
 
+    def set_halo_p2p(self, on):
+        check(self.L.qgcm_hip_comm_set_halo_p2p(self.h, int(on)))
+
     def slab_steps(self, s0, n):
         check(self.L.qgcm_hip_slab_steps(self.h, int(s0), int(n)))
         self._done()
