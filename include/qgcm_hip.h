@@ -213,6 +213,21 @@ int qgcm_hip_oml(qgcm_hip_handle h);          /* replaces "call oml", src/q-gcm.
 /* entoc(nxpo,nypo) (or NULL) and diag[5] = xon(1), cfraoc, centoc, enisoc(1), eninoc(1); synchronous */
 int qgcm_hip_oml_get_diag(qgcm_hip_handle h, double *entoc, double *diag);
 
+/* ---- validity scan -----------------------------------------
+ * Ocean part of "call valids (solnok)" (src/q-gcm.F:1278; src/valsubs.F:272-527) on the device: instead of
+ * pulling po, qo (44 MB at 5 km) every valday, 14 + nlo doubles and the verdict come back.
+ *   out[0..13]  min, max of po, qo, sst, wekto, full layer thickness top / intermediate / bottom
+ *   out[14..]   hfbad(1..nlo): per cent of the basin where layer k is thinner than thkmin = 100 m
+ *               (evaluated, as in the reference, only when some thickness is <= thkmin; else 0)
+ *   *solnok     0 if |po| >= 1e4, |qo| >= 0.05, |sst| >= 75, |wekto| >= 1e-3 or hfbad(k) > 20 (the reference's
+ *               limits, src/valsubs.F:78-97), else 1.  sst / wekto are scanned when the mixed layer is
+ *               initialised (their entries stay at +/-1e30 otherwise).
+ * Bitwise the reference's numbers (min / max / quarter-integer sums are order independent). The
+ * neighbourhood print-out of a failing run stays on the host (pull the state, call the reference's valids).
+ * qgcm_hip_set_dtopoc: bottom topography dtopoc(nxpo,nypo) of MODULE occonst (NULL = flat). Synchronous. */
+int qgcm_hip_set_dtopoc(qgcm_hip_handle h, const double *dtopoc);
+int qgcm_hip_valids(qgcm_hip_handle h, double *out, int *solnok);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
  * the whole region, measured on the handle's stream. */

@@ -67,13 +67,15 @@ for f in vorsubs qgosubs ocisubs conhoms; do $FCO $Q -c -I"$SRC" "$SRC/$f.F"; do
 $FCO $Q -c -I"$SRC" "$SRC/intrfac_data.F"
 $FCO -c -I"$SRC" "$SRC/radiate_data.F"
 $FCB $Q -c -I"$SRC" "$SRC/omlsubs.F"
+# validity scan
+$FCO $Q -c -I"$SRC" "$SRC/valsubs.F"
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_harness.F90"
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_oml.F90"
 
 $FC -shared -fopenmp -o "$OUT/libqgcm_ref_$CFG.so" \
     parameters_data.o occonst_data.o ochomog_data.o ocstate_data.o monitor_data.o \
     intsubs.o eigmode.o fftsubs.o vorsubs.o qgosubs.o ocisubs.o conhoms.o \
-    intrfac_data.o radiate_data.o omlsubs.o qgcm_ref_harness.o qgcm_ref_oml.o \
+    intrfac_data.o radiate_data.o omlsubs.o valsubs.o qgcm_ref_harness.o qgcm_ref_oml.o \
     -L"$MKLDIR" -Wl,--no-as-needed -lmkl_gf_lp64 -lmkl_sequential -lmkl_core -Wl,--as-needed -Wl,-rpath,"$MKLDIR" -Wl,-rpath,/opt/rocm/lib/llvm/lib
 
 echo "built $OUT/libqgcm_ref_$CFG.so"

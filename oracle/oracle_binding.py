@@ -60,6 +60,7 @@ def lib():
         L.qgo_oml_get.argtypes = [C.c_void_p] + [dp] * 4
         L.qgo_oml.argtypes = [C.c_void_p]
         L.qgo_steps_oml.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.qgo_valids.argtypes = [C.c_void_p, dp, dp]
         _lib = L
     return _lib
 
@@ -261,6 +262,13 @@ class Oracle:
 
     def steps_oml(self, s0, n):
         self.L.qgo_steps_oml(self.h, int(s0), int(n))
+
+    def valids(self, dtopoc=None):
+        """(solnok, out) of the ocean part of valids (src/valsubs.F:272-527)."""
+        out = np.zeros(14 + self.nl)
+        d = None if dtopoc is None else np.asfortranarray(dtopoc, dtype=np.float64)
+        ok = self.L.qgo_valids(self.h, None if d is None else _dp(d), _dp(out))
+        return bool(ok), out
 
     def project(self):
         w = self._f3()

@@ -1577,3 +1577,60 @@ void qgo_steps_oml(qgo_ctx *c, int s0, int n) {
     }
   }
 }
+
+
+/* ================================================================== */
+/* valids, ocean part: src/valsubs.F:272-527.        */
+/* out = pocmin,pocmax,qocmin,qocmax,sstmin,sstmax,wekmin,wekmax,       */
+/*       hfmint,hfmaxt,hfmini,hfmaxi,hfminb,hfmaxb, hfbad(1..nlo) [%]   */
+/* returns solnok.  sst / wekto are scanned only when the mixed layer   */
+/* is initialised (otherwise their entries keep +/-bignum).             */
+/* ================================================================== */
+int qgo_valids(qgo_ctx *c, const double *dtopoc, double *out) {
+  const int nx = c->nx, ny = c->ny, nl = c->nl;
+  const double bignum = 1.0e30, wtoext = 1.0e-3, sstext = 75.0, pocext = 1.0e4, qocext = 0.05; /* :78-82 */
+  const double thkmin = 100.0, critpc = 20.0;                                                    /* :96-97 */
+  double mn[7], mx[7];
+  for (int q = 0; q < 7; ++q) { mn[q] = bignum; mx[q] = -bignum; }
+#define MM(q, v) do { double v_ = (v); if (v_ < mn[q]) mn[q] = v_; if (v_ > mx[q]) mx[q] = v_; } while (0)
+  for (size_t t = 0; t < (size_t)nx * ny * nl; ++t) { MM(0, c->po[t]); MM(1, c->qo[t]); }
+  if (c->sst)
+    for (size_t t = 0; t < (size_t)c->nxt * (ny - 1); ++t) { MM(2, c->sst[t]); MM(3, c->wekto[t]); }
+  double rg[64], eta[64], hfbad[64];
+  for (int k = 0; k < nl - 1; ++k) rg[k] = 1.0 / c->gpoc[k];
+  const size_t N = (size_t)nx * ny;
+  for (int pass = 0; pass < 2; ++pass) {
+    double hfmina = fmin(mn[4], fmin(mn[5], mn[6]));
+    if (pass == 1 && !(hfmina <= thkmin)) break;
+    for (int k = 0; k < nl; ++k) hfbad[k] = 0.0;
+    for (int j = 1; j <= ny; ++j)
+      for (int i = 1; i <= nx; ++i) {
+        const size_t o = (size_t)(i - 1) + (size_t)nx * (j - 1);
+        const double w = ((i == 1 || i == nx) ? 0.5 : 1.0) * ((j == 1 || j == ny) ? 0.5 : 1.0);
+        for (int k = 0; k < nl - 1; ++k) eta[k] = rg[k] * (c->po[o + N * (k + 1)] - c->po[o + N * k]);
+        double hf = c->hoc[0] - eta[0];
+        if (pass == 0) MM(4, hf); else if (hf < thkmin) hfbad[0] += w;
+        for (int k = 1; k < nl - 1; ++k) {
+          hf = c->hoc[k] - eta[k] + eta[k - 1];
+          if (pass == 0) MM(5, hf); else if (hf < thkmin) hfbad[k] += w;
+        }
+        hf = c->hoc[nl - 1] + eta[nl - 2] - (dtopoc ? dtopoc[o] : 0.0);
+        if (pass == 0) MM(6, hf); else if (hf < thkmin) hfbad[nl - 1] += w;
+      }
+  }
+#undef MM
+  const double ocnorm = 1.0 / ((double)c->nxt * (double)(ny - 1));
+  for (int k = 0; k < nl; ++k) hfbad[k] = 100.0 * hfbad[k] * ocnorm;
+  int ok = 1;
+  if (fabs(mn[0]) >= pocext || fabs(mx[0]) >= pocext) ok = 0;
+  if (fabs(mn[1]) >= qocext || fabs(mx[1]) >= qocext) ok = 0;
+  if (c->sst) {
+    if (fabs(mn[2]) >= sstext || fabs(mx[2]) >= sstext) ok = 0;
+    if (fabs(mn[3]) >= wtoext || fabs(mx[3]) >= wtoext) ok = 0;
+  }
+  for (int k = 0; k < nl; ++k)
+    if (hfbad[k] > critpc) ok = 0; /* spfail = .false.: percentage criterion, :507-512 */
+  for (int q = 0; q < 7; ++q) { out[2 * q] = mn[q]; out[2 * q + 1] = mx[q]; }
+  for (int k = 0; k < nl; ++k) out[14 + k] = hfbad[k];
+  return ok;
+}

@@ -85,6 +85,10 @@ void qgo_oml_get(qgo_ctx *c, double *sst, double *sstm, double *entoc, double *s
 void qgo_oml(qgo_ctx *c);
 void qgo_steps_oml(qgo_ctx *c, int s0, int n); /* oml, qgostep, ocinvq, ocqbdy (+ averaging incl. sst) */
 
+/* valids, ocean part (src/valsubs.F:272-527): out = min/max of po, qo, sst, wekto, full layer thickness
+ * top / intermediate / bottom (14 values), hfbad(1..nlo) in per cent; returns solnok. dtopoc may be NULL (flat). */
+int qgo_valids(qgo_ctx *c, const double *dtopoc, double *out);
+
 #ifdef __cplusplus
 }
 #endif

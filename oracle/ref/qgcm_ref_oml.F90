@@ -22,6 +22,7 @@ module qgcm_ref_oml
   use qgosubs
   use ocisubs
   use vorsubs
+  use valsubs
   implicit none
 
 contains
@@ -119,5 +120,17 @@ contains
       endif
     enddo
   end subroutine ref_steps_oml
+
+  ! valids (src/valsubs.F:43-627): only the verdict is observable, its extremes are local variables
+  subroutine ref_valids(ok, dtop_in) bind(C, name='ref_valids')
+    integer(c_int), intent(out) :: ok
+    real(c_double), intent(in) :: dtop_in(nxpo,nypo)
+    logical :: solnok
+    dtopoc = dtop_in
+    solnok = .true.
+    call valids (solnok)
+    ok = 0
+    if (solnok) ok = 1
+  end subroutine ref_valids
 
 end module qgcm_ref_oml

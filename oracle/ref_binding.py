@@ -168,6 +168,13 @@ class RefLib:
         self.lib.ref_steps_oml.argtypes = [C.c_int, C.c_int]
         run_big_stack(self.lib.ref_steps_oml, int(s0), int(n))
 
+    def valids(self, dtopoc=None):
+        """The reference's verdict solnok (src/valsubs.F:43); its prints go to stdout."""
+        d = self._f2() if dtopoc is None else np.asfortranarray(dtopoc, dtype=np.float64)
+        ok = C.c_int()
+        run_big_stack(self.lib.ref_valids, C.byref(ok), _dp(d))
+        return bool(ok.value)
+
     def set_cyc_forcing(self, txis, txin, enis=None, enin=None):
         es = np.zeros(self.nl - 1) if enis is None else np.ascontiguousarray(enis, dtype=np.float64)
         en = np.zeros(self.nl - 1) if enin is None else np.ascontiguousarray(enin, dtype=np.float64)

@@ -19,6 +19,7 @@
 #include "k_misc.h"
 #include "k_cyclic.h"
 #include "k_oml.h"
+#include "k_valids.h"
 #include "slab_comm.h"
 
 static thread_local char g_err[512] = "";
@@ -88,6 +89,8 @@ struct qgcm_hip_ctx {
     double *fnet = nullptr, *wekto = nullptr, *xfo = nullptr, *taux = nullptr, *tauy = nullptr;
     double *partA = nullptr, *partB = nullptr, *diag = nullptr;
   } oml;
+  // validity scan (qgcm_hip_valids): partials, results, optional bottom topography
+  double *val_part = nullptr, *val_out = nullptr, *dtopoc = nullptr;
   // y-slab exchanges over RCCL (qgcm_hip_comm_init); slab-step graphs keyed like `graphs`
   QgSlabComm *sc_comm = nullptr;
   std::map<int, hipGraphExec_t> slab_graphs;
@@ -241,6 +244,9 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
       if (p) hipFree(p);
     delete m;
   }
+  double *vp[] = {c->val_part, c->val_out, c->dtopoc};
+  for (double *p : vp)
+    if (p) hipFree(p);
   double *omp[] = {c->oml.sst[0], c->oml.sst[1], c->oml.sst[2], c->oml.fnet, c->oml.wekto, c->oml.xfo,
                    c->oml.taux, c->oml.tauy, c->oml.partA, c->oml.partB, c->oml.diag};
   for (double *p : omp)
@@ -1109,6 +1115,71 @@ extern "C" int qgcm_hip_oml_get_diag(qgcm_hip_handle c, double *entoc, double *d
     diag[0] = h.xon[0]; diag[1] = d[0]; diag[2] = d[1];
     diag[3] = g.cyc ? h.enisoc[0] : 0.0; diag[4] = g.cyc ? h.eninoc[0] : 0.0;
   }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// validity scan
+// ---------------------------------------------------------------------------
+extern "C" int qgcm_hip_set_dtopoc(qgcm_hip_handle c, const double *dtopoc) {
+  if (check_ready(c, "qgcm_hip_set_dtopoc")) return 1;
+  const QgGeom &g = c->g;
+  if (!dtopoc) {
+    if (c->dtopoc) hipFree(c->dtopoc);
+    c->dtopoc = nullptr;
+    return 0;
+  }
+  if (!c->dtopoc && dalloc(&c->dtopoc, (size_t)g.ldx * g.ny)) return 1;
+  return upload2d(c, c->dtopoc, g.ldx, dtopoc, g.nx, g.ny);
+}
+
+extern "C" int qgcm_hip_valids(qgcm_hip_handle c, double *out, int *solnok) {
+  if (check_ready(c, "qgcm_hip_valids")) return 1;
+  if (!c->whole) QG_FAIL("qgcm_hip_valids: only for a handle that owns the whole domain");
+  const QgGeom &g = c->g;
+  if (g.nl < 2 || g.nl > 4) QG_FAIL("qgcm_hip_valids: unsupported nlo");
+  const int nres = 2 * VAL_NMM + g.nl + 1;
+  if (!c->val_part) {
+    if (dalloc(&c->val_part, (size_t)(2 * VAL_NMM + QG_MAXL) * VAL_NB)) return 1;
+    if (dalloc(&c->val_out, (size_t)2 * VAL_NMM + QG_MAXL + 1)) return 1;
+  }
+  QgValidsParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.po = c->p[c->ip];
+  P.qo = c->q[c->iq];
+  if (c->oml.on) {
+    P.sst = c->oml.sst[c->oml.is];
+    P.wekto = c->oml.wekto;
+    P.ldt = c->oml.ldt;
+  }
+  P.dtopoc = c->dtopoc;
+  for (int k = 0; k < g.nl - 1; ++k) P.rgpoc[k] = 1.0 / c->prm.gpoc[k]; // src/valsubs.F:390-392
+  for (int k = 0; k < g.nl; ++k) P.hoc[k] = c->prm.hoc[k];
+  P.part = c->val_part;
+  P.out = c->val_out;
+  P.ocnorm = 1.0 / ((double)g.nxt * (double)(g.ny - 1));
+  switch (g.nl) {
+    case 2:
+      hipLaunchKernelGGL((k_valids_scan<2>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);
+      hipLaunchKernelGGL((k_valids_final<2>), dim3(1), dim3(VAL_NT), 0, c->stream, P);
+      break;
+    case 3:
+      hipLaunchKernelGGL((k_valids_scan<3>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);
+      hipLaunchKernelGGL((k_valids_final<3>), dim3(1), dim3(VAL_NT), 0, c->stream, P);
+      break;
+    default:
+      hipLaunchKernelGGL((k_valids_scan<4>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);
+      hipLaunchKernelGGL((k_valids_final<4>), dim3(1), dim3(VAL_NT), 0, c->stream, P);
+      break;
+  }
+  HIPCHECK(hipGetLastError());
+  double h[2 * VAL_NMM + QG_MAXL + 1];
+  HIPCHECK(hipMemcpyAsync(h, c->val_out, sizeof(double) * nres, hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (out)
+    for (int q = 0; q < nres - 1; ++q) out[q] = h[q];
+  if (solnok) *solnok = h[nres - 1] > 0.5 ? 1 : 0;
   return 0;
 }
 

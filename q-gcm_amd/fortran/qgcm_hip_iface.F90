@@ -153,6 +153,18 @@ module qgcm_hip_iface
       type(c_ptr), value :: h
       real(c_double), intent(out) :: entoc(*), diag(5)
     end function
+    ! validity scan: ocean part of "call valids (solnok)" (src/q-gcm.F:1278) on the device
+    integer(c_int) function qgcm_hip_set_dtopoc(h, dtopoc) bind(C, name='qgcm_hip_set_dtopoc')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: dtopoc(*)
+    end function
+    integer(c_int) function qgcm_hip_valids(h, out, solnok) bind(C, name='qgcm_hip_valids')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: out(*)
+      integer(c_int), intent(out) :: solnok
+    end function
     ! y-slab runs, one process per GPU: rendezvous id (rank 0), communicator, whole distributed steps
     ! (the library issues the RCCL exchanges itself; include/qgcm_hip.h)
     integer(c_int) function qgcm_hip_comm_unique_id(id, nbytes) bind(C, name='qgcm_hip_comm_unique_id')

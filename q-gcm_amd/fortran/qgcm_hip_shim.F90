@@ -292,3 +292,34 @@ contains
   end subroutine qgcm_hip_oml_pull
 
 end module omlsubs
+
+
+!-----------------------------------------------------------------------
+! MODULE valsubs_hip: `valids_hip (solnok)` for the call site src/q-gcm.F:1278 (SURVEY 8 row f2).
+! The scan of src/valsubs.F:272-527 runs on the device (20 doubles back instead of po, qo);
+! only after a negative verdict is the state pulled so that the reference's own valids can
+! print its neighbourhood diagnostics:
+!       call valids_hip (solnok)
+!       if (.not.solnok) then
+!         call qgcm_hip_pull ; call valids (solnok)      ! reference routine, unchanged
+!       endif
+!-----------------------------------------------------------------------
+module valsubs_hip
+  use iso_c_binding
+  use qgcm_hip_iface
+  use qgcm_hip_state
+  implicit none
+  private
+  public :: valids_hip
+contains
+  subroutine valids_hip (solnok, extremes)
+    use parameters, only : nlo
+    logical, intent(inout) :: solnok
+    double precision, intent(out), optional :: extremes(14 + nlo)
+    real(c_double) :: res(14 + nlo)
+    integer(c_int) :: ok
+    call qgcm_hip_check(qgcm_hip_valids(qgcm_hip_handle, res, ok), 'qgcm_hip_valids')
+    if (ok == 0) solnok = .false.
+    if (present(extremes)) extremes = res
+  end subroutine valids_hip
+end module valsubs_hip

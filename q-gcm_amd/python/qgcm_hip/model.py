@@ -177,6 +177,18 @@ class OceanModel:
     def sync(self):
         check(self.L.qgcm_hip_sync(self.h))
 
+    # -- validity scan (`call valids (solnok)`, src/q-gcm.F:1278) --
+    def set_dtopoc(self, dtopoc):
+        check(self.L.qgcm_hip_set_dtopoc(self.h, _dp(_f(dtopoc))))
+
+    def valids(self):
+        """(solnok, out): out = min/max of po, qo, sst, wekto, layer thickness top/intermediate/bottom,
+        then hfbad(1..nlo) in per cent (src/valsubs.F:272-527)."""
+        out = np.zeros(14 + self.cfg.nlo)
+        ok = C.c_int()
+        check(self.L.qgcm_hip_valids(self.h, _dp(out), C.byref(ok)))
+        return bool(ok.value), out
+
     # -- ocean mixed layer (`call oml`, src/q-gcm.F:1232; SURVEY 8 row f1) -------
     def oml_init(self, om):
         """Switch the mixed layer on (om: qgcm_hip.config.OmlConfig): steps() then runs oml before
