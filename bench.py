@@ -97,6 +97,7 @@ def cpu_baseline(cfg, po, wek, budget_s=15.0):
             r.set_p(po, po)
             r.set_forcing(wek, zeros2, np.zeros(cfg.nlo - 1))
             kind, model = "reference", r
+            ref_binding.set_threads(cores)
     except Exception as e:  # fall back to the port, say why
         print("cpu_baseline: reference library unusable (%s); timing the C port" % e, file=sys.stderr)
     if model is None:
@@ -116,7 +117,24 @@ def cpu_baseline(cfg, po, wek, budget_s=15.0):
     model.steps(16, n)
     dt = time.perf_counter() - t0
     sps = n / dt
-    return {"value": round(sps, 3), "unit": "steps/s", "cores": cores, "kind": kind,
+    # the same on ONE thread (SURVEY 8d asks for both): the OpenMP runtime is already in the process
+    one = None
+    try:
+        def set_threads(k):
+            if kind == "port":
+                ob.set_threads(k)
+            else:
+                ref_binding.set_threads(k)  # applied on the thread that runs the reference (oracle/ref_binding.py)
+        set_threads(1)
+        model.steps(16 + n, 2)
+        t0 = time.perf_counter()
+        n1 = int(max(5, min(40, 4.0 / (per * min(cores, 8)))))
+        model.steps(18 + n, n1)
+        one = round(n1 / (time.perf_counter() - t0), 3)
+        set_threads(cores)
+    except Exception as e:  # noqa: BLE001
+        print("cpu_baseline: single-thread timing skipped (%r)" % (e,), file=sys.stderr)
+    return {"value": round(sps, 3), "unit": "steps/s", "cores": cores, "kind": kind, "value_1_thread": one,
             "ms_per_step": round(1e3 / sps, 4), "model_years_per_day": round(cfg.model_years_per_day(sps), 2),
             "sample": "%d ocean steps of the same %s workload (Gaussian-eddy IC, double-gyre wind), "
                       "%d OpenMP threads, %.1f s" % (n, WORKLOAD, cores, dt)}

@@ -35,6 +35,12 @@ CONFIGS = {
 
 
 _LOADED_CFG = None
+_OMP_THREADS = None  # set_threads(): thread count for the reference's OpenMP regions (None = runtime default)
+
+
+def set_threads(n):
+    global _OMP_THREADS
+    _OMP_THREADS = n
 
 
 def lib_path(cfg):
@@ -62,6 +68,14 @@ def run_big_stack(fn, *args):
 
     def tgt():
         try:
+            if _OMP_THREADS is not None:
+                # OpenMP's num-threads setting is per initial thread: it has to be made on THIS thread
+                for name in ("libomp.so", "/opt/rocm/lib/llvm/lib/libomp.so"):
+                    try:
+                        C.CDLL(name).omp_set_num_threads(int(_OMP_THREADS))
+                        break
+                    except OSError:
+                        continue
             out["r"] = fn(*args)
         except BaseException as e:  # pragma: no cover
             out["e"] = e
