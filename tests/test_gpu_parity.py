@@ -196,6 +196,67 @@ def test_fast_dst_grid_vs_oracle():
         o.close()
 
 
+def test_dynamic_topography_and_entrainment_fields():
+    """ddynoc != 0 (the reference's topography term, src/ocisubs.F:124, src/vorsubs.F:296) and entoc != 0: qgostep
+    and ocqbdy stay bit exact against the oracle, whole steps within tolerance; then the same model with the
+    fields reset to zero (forcing changed after graphs were captured)."""
+    import oracle_binding as ob
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("box_med")
+    i = np.arange(cfg.nxpo)[:, None] / (cfg.nxpo - 1.0)
+    j = np.arange(cfg.nypo)[None, :] / (cfg.nypo - 1.0)
+    ddyn = np.asfortranarray(2.0e-6 * np.sin(3 * np.pi * i) * np.cos(2 * np.pi * j))
+    ent = np.asfortranarray(1.0e-7 * np.cos(2 * np.pi * i) * np.sin(np.pi * j))
+    o = ob.Oracle(cfg.nxpo, cfg.nypo, cfg.nlo, cfg.cyclic, cfg.fnot, cfg.beta, cfg.dxo, cfg.dto, cfg.delek, cfg.bccooc,
+                  cfg.ah2oc, cfg.ah4oc, cfg.hoc, cfg.gpoc, cfg.yporel(), ddyn)
+    o0 = make_oracle(cfg)
+    m = OceanModel(cfg, ddynoc=ddyn)
+    m0 = OceanModel(cfg)
+    try:
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        xon = np.zeros(cfg.nlo - 1)
+        for mod in (o, m):
+            mod.set_p(po, 0.99 * po)
+            mod.set_forcing(wek, ent, xon)
+            mod.qgostep()
+        for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
+            assert np.array_equal(x, y), f            # bit exact
+        for mod in (o, m):
+            mod.ocinvq()
+            mod.ocqbdy()
+            mod.steps(2, 60) if mod is o else mod.steps(60, s0=2)
+        for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
+            assert relerr(x, y) < 1e-10, f
+        # zero fields again (m0 never saw a non-zero field; m switches back)
+        zero = np.zeros_like(ent)
+        for mod in (o0, m0):
+            mod.set_p(po, 0.99 * po)
+            mod.set_forcing(wek, zero, xon)
+        m0.steps(55, s0=1)
+        o0.steps(1, 55)
+        for f, x, y in zip(FIELDS, m0.get_state(), o0.get_state()):
+            assert relerr(x, y) < 1e-10, f
+        m.set_forcing(wek, zero, xon)
+        m.set_p(po, 0.99 * po)
+        o.set_forcing(wek, zero, xon)
+        o.set_p(po, 0.99 * po)
+        m.steps(55, s0=1)
+        o.steps(1, 55)
+        for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
+            assert relerr(x, y) < 1e-10, f
+        m0.set_p(po, 0.99 * po)
+        o0.set_p(po, 0.99 * po)
+        m0.qgostep()
+        o0.qgostep()
+        for f, x, y in zip(FIELDS, m0.get_state(), o0.get_state()):
+            assert np.array_equal(x, y), f
+    finally:
+        for mod in (m, m0, o, o0):
+            mod.close()
+
+
 def test_fused_inverse_transform_unpack_bitwise():
     """k_dst64_unpack (inverse row transform + modes -> layers + boundary PV in one launch) against
     the separate k_dst64 / k_unpack_box (/ k_ocqbdy) launches: same expressions, so bitwise equal --
