@@ -27,7 +27,9 @@
 #include "qgcm_dev.h"
 
 #define TEND_TX 64
+#ifndef TEND_TY
 #define TEND_TY 8
+#endif
 #define TEND_NT 256
 
 template <bool CYC>
@@ -141,7 +143,10 @@ __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTilin
 }
 
 template <int NL, bool CYC>
-__global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
+#ifndef TEND_WAVES_PER_EU
+#define TEND_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P) {
   constexpr int TX = TEND_TX, TY = TEND_TY;
   constexpr int W3 = TX + 6, H3 = TY + 6; // pom tile, halo 3
   constexpr int W2 = TX + 4, H2 = TY + 4; // d2 tile, halo 2
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   constexpr int N1 = (H1 * W1 + TEND_NT - 1) / TEND_NT;
   __shared__ double sp[H3 * W3];
   __shared__ double sd2[H2 * W2];
-  __shared__ double sd4[H1 * W1];
+  // Del^4 tile: lives in the pom tile's storage (dead once Del^2 is formed; refilled only after the layer's
+  // last barrier), which keeps the workgroup at 4 x 30 KB (TY = 8) resp. 3 x 51 KB (TY = 20) per CU
+  double *sd4 = sp;
+  static_assert(H1 * W1 <= H3 * W3, "Del^4 tile must fit into the pom tile");
   __shared__ double spo[H1 * W1];
   __shared__ double sqo[H1 * W1];
 
@@ -179,50 +187,37 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
   constexpr int RPT = TY / (TEND_NT / TX); // rows per thread
   const double bcf = P.bcfaco, dxom2 = P.dxom2;
 
-  // ---- global offsets of the elements this thread stages (same for every layer)
-  long o3[N3], o1[N1];
-#pragma unroll
-  for (int e = 0; e < N3; ++e) {
+  // ---- global offsets of the elements this thread stages (same for every layer); recomputed where they are
+  // used instead of being kept in registers (the integer pipe has room, the register file has not)
+  auto off3 = [&](int e) -> long {
     int idx = tid + e * TEND_NT;
     int lx = idx % W3, ly = idx / W3;
     int gi = i0 - 3 + lx, gj = j0 - 3 + ly;
     bool ok = idx < H3 * W3 && gj >= 1 && gj <= ny && (CYC ? (gi >= -2 && gi <= nx + 3) : (gi >= 1 && gi <= nx));
-    o3[e] = ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
-  }
-#pragma unroll
-  for (int e = 0; e < N1; ++e) {
+    return ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
+  };
+  auto off1 = [&](int e) -> long {
     int idx = tid + e * TEND_NT;
     int lx = idx % W1, ly = idx / W1;
     int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
     bool ok = idx < H1 * W1 && gj >= 1 && gj <= ny && (CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx));
-    o1[e] = ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
-  }
+    return ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
+  };
   double r3[N3], rp[N1], rq[N1];
 #pragma unroll
-  for (int e = 0; e < N3; ++e) r3[e] = o3[e] >= 0 ? P.pom[o3[e]] : 0.0;
+  for (int e = 0; e < N3; ++e) {
+    const long o = off3(e);
+    r3[e] = o >= 0 ? P.pom[o] : 0.0;
+  }
 #pragma unroll
   for (int e = 0; e < N1; ++e) {
-    rp[e] = o1[e] >= 0 ? P.po[o1[e]] : 0.0;
-    rq[e] = o1[e] >= 0 ? P.qo[o1[e]] : 0.0;
+    const long o = off1(e);
+    rp[e] = o >= 0 ? P.po[o] : 0.0;
+    rq[e] = o >= 0 ? P.qo[o] : 0.0;
   }
-  // ---- epilogue operands of this thread's own points (prefetched) -----------
-  double e_qm[NL][RPT], e_qo[NL][RPT], e_wek[RPT], e_ent[RPT], e_ddy[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    int ly = ty0 + r * (TEND_NT / TX);
-    int gi = i0 + tx, gj = j0 + ly;
-    bool in = gi <= T.imax && gj <= T.jmax;
-    long o = in ? (long)(gj - 1) * ldx + (gi - 1) : 0;
-    bool row = in && (gj + joff == 1 || gj + joff == nyg);
-    e_wek[r] = in ? P.wekpo[o] : 0.0;
-    e_ent[r] = in ? P.entoc[o] : 0.0;
-    e_ddy[r] = in ? P.ddynoc[o] : 0.0;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      e_qm[k][r] = in ? P.qnew[fs * k + o] : 0.0;
-      e_qo[k][r] = row ? P.qo[fs * k + o] : 0.0;
-    }
-  }
+  // ---- epilogue operands of this thread's own points: requested while the LAST layer is computed (the
+  // registers of the layer prefetch are free by then); the old qo of the wall rows is read in the epilogue
+  double e_qm[NL][RPT], e_wek[RPT], e_ent[RPT], e_ddy[RPT];
 
   double dq[NL][RPT];
   double d2bot[RPT];
@@ -250,11 +245,28 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
       const double *po = P.po + fs * (k + 1);
       const double *qo = P.qo + fs * (k + 1);
 #pragma unroll
-      for (int e = 0; e < N3; ++e) r3[e] = o3[e] >= 0 ? pom[o3[e]] : 0.0;
+      for (int e = 0; e < N3; ++e) {
+        const long o = off3(e);
+        r3[e] = o >= 0 ? pom[o] : 0.0;
+      }
 #pragma unroll
       for (int e = 0; e < N1; ++e) {
-        rp[e] = o1[e] >= 0 ? po[o1[e]] : 0.0;
-        rq[e] = o1[e] >= 0 ? qo[o1[e]] : 0.0;
+        const long o = off1(e);
+        rp[e] = o >= 0 ? po[o] : 0.0;
+        rq[e] = o >= 0 ? qo[o] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        int ly = ty0 + r * (TEND_NT / TX);
+        int gi = i0 + tx, gj = j0 + ly;
+        bool in = gi <= T.imax && gj <= T.jmax;
+        long o = in ? (long)(gj - 1) * ldx + (gi - 1) : 0;
+        e_wek[r] = in ? P.wekpo[o] : 0.0;
+        e_ent[r] = in ? P.entoc[o] : 0.0;
+        e_ddy[r] = in ? P.ddynoc[o] : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < NL; ++kk) e_qm[kk][r] = in ? P.qnew[fs * kk + o] : 0.0;
       }
     }
     // ---- Del^2(pom) on the halo-2 region (qgosubs.F:94-127) ----------
@@ -324,11 +336,12 @@ __global__ __launch_bounds__(TEND_NT) void k_tend(const QgTendParams P) {
     int gi = i0 + tx, gj = j0 + ly;
     if (gi > T.imax || gj > T.jmax) continue;
     double dqp[NL], qmp[NL], qop[NL];
+    const bool wallrow = (gj + joff == 1 || gj + joff == nyg);
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       dqp[k] = dq[k][r];
       qmp[k] = e_qm[k][r];
-      qop[k] = e_qo[k][r];
+      qop[k] = wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
     }
     tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
   }
