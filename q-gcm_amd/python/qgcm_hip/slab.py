@@ -5,18 +5,24 @@ The reference is a single-process OpenMP code; this decomposition is new design
 never split, so the tendency kernel, the row transforms and the unpack stay local.
 Per ocean step the ranks exchange
 
-  * the slab summaries of the tridiagonal sweeps along y (ONE all-gather of
-    4*nlo*nk doubles: both sweeps are linear in the values entering a slab, see
-    k_thomas.h, instead of two all-to-all transposes of the whole work array),
-  * the nlo partial area integrals (all-gather, summed in rank order so every rank
-    gets bit-identical constraint coefficients),
+  * the slab summaries of the tridiagonal sweeps along y and of the area integrals (ONE
+    all-gather of 7*nlo*nk doubles: both sweeps and the column sums are linear in the
+    values entering a slab, see k_thomas.h, instead of two all-to-all transposes of the
+    whole work array and an all-reduce); every rank derives bit-identical constraint
+    coefficients from it,
   * halo rows of the new po (3 rows: del-6 of the lagged field) and qo (1 row).
+
+The exchanges are issued either from here (torch.distributed between the stage calls) or
+by the library itself (`use_library_exchanges`: RCCL from C++, qgcm_hip_slab_steps).
 
 `SlabOcean` is the orchestration; it is independent of where the slab kernels
 run (`HipSlab`: the C ABI on a GPU) and of the transport (`LocalComm`: several
 slabs in one process, used to test the decomposition on one GPU; `DistComm`:
 torch.distributed, "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests).
 All message buffers are torch tensors.
+
+Import order: torch bundles its own HIP runtime; a process that uses torch (these transports do) must import it
+before the first OceanModel / HipSlab loads libqgcm_hip.so, otherwise torch reports "No HIP GPUs are available".
 """
 import ctypes as C
 

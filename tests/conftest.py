@@ -29,6 +29,14 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(_usable_cores(), 8)))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 
+# torch bundles its own HIP runtime: when torch is used at all (the slab transports, torch.distributed) it has to
+# be imported before libqgcm_hip.so pulls in /opt/rocm's copy, or torch finds "no HIP GPUs" afterwards.
+try:
+    import torch  # noqa: F401,E402
+except Exception:  # pragma: no cover - torch is optional for the product
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
