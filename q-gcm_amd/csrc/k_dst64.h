@@ -429,6 +429,23 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
   }
   __syncthreads();
   const int nx = U.g.nx, nyg = U.g.nyg, joff = U.g.joff;
+  // y-slab halo messages (k_halo_pack's layout: [k][3 rows][ldx] of p, then [k][ldx] of q): the first / last three
+  // owned rows go to the lower / upper neighbour straight from here (no separate pack launch)
+  const int jlo = U.g.jlo, jhi = U.g.jhi, ldxm = U.g.ldx;
+  auto msg_p = [&](int gi, int gj, const double *pl) {
+    if (U.msg_lo && gj - jlo < 3) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) U.msg_lo[((long)k * 3 + (gj - jlo)) * ldxm + (gi - 1)] = pl[k];
+    }
+    if (U.msg_hi && jhi - gj < 3) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) U.msg_hi[((long)k * 3 + (gj - (jhi - 2))) * ldxm + (gi - 1)] = pl[k];
+    }
+  };
+  auto msg_q = [&](int gi, int gj, int k, double q) {
+    if (U.msg_lo && gj == jlo) U.msg_lo[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
+    if (U.msg_hi && gj == jhi) U.msg_hi[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
+  };
   // unpack_point of k_misc.h with the transformed rows taken from LDS; sel: 0 row a, 1 row b, -1 wall row;
   // ocv: prefetched ochom values of the point, or nullptr (read them here)
   auto point = [&](int gi, int gj, int sel, const double *ocv, double *pl) {
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
     }
   };
   // boundary PV of one wall point (k_unpack_box / k_ocqbdy): by = beta*yporel(j), dd = ddynoc(i,j)
-  auto bdy_q = [&](long o, const double *pl, const double *pin, double by, double dd) {
+  auto bdy_q = [&](long o, const double *pl, const double *pin, double by, double dd, int gi, int gj) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       double ap;
@@ -460,6 +477,7 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
       double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
       if (k == NL - 1) q = q + dd;
       B.qo[fs * k + o] = q;
+      msg_q(gi, gj, k, q);
     }
   };
   // wall columns (W by wave 0, E by wave 1)
@@ -473,10 +491,11 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
       point(gw, gj, r, ocw[r], pl);
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
+      msg_p(gw, gj, pl);
       if (BDY) {
         double pin[NL];
         point(gn, gj, r, ocn[r], pin);
-        bdy_q(o, pl, pin, byw[r], ddw[r]);
+        bdy_q(o, pl, pin, byw[r], ddw[r], gw, gj);
       }
     }
   }
@@ -494,6 +513,11 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
       point(gi, gj, r, oc[r][it], pl);
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
+      msg_p(gi, gj, pl);
+      if ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi)) { // interior columns of the q row: set by k_tend
+#pragma unroll
+        for (int k = 0; k < NL; ++k) msg_q(gi, gj, k, B.qo[fs * k + o]);
+      }
     }
   }
   // wall rows of the basin (G = 1, nyg): done by the workgroup of the first / last interior row
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
       for (int k = 0; k < NL; ++k) U.pnew[fs * k + ow] = pw[k];
       if (BDY) {
         point(gi, gj, r, nullptr, pl);
-        bdy_q(ow, pw, pl, B.beta * B.yporel[wall - 1], B.ddynoc[ow]);
+        bdy_q(ow, pw, pl, B.beta * B.yporel[wall - 1], B.ddynoc[ow], gi, wall);
       }
     }
   }

@@ -98,6 +98,7 @@ struct QgUnpackParams {
   const double *wrk;
   const double *ochom;
   double *pnew; // old pom buffer, receives the new po
+  double *msg_lo, *msg_hi; // y-slab halo messages (k_misc.h layout) written by the fused unpack, or nullptr
   const QgScalars *sc;
   const double *pch1, *pch2, *pbh; // cyclic (ny, nl-1), (ny)
   double ctm2l[QG_MAXL * QG_MAXL]; // (m,k) at m + nl*k

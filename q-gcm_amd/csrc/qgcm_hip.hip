@@ -839,7 +839,7 @@ static bool can_fuse_dst_unpack(const qgcm_hip_ctx *c) {
          c->g.nl >= 2 && c->g.nl <= 4;
 }
 
-static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
+static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nullptr, double *msg_hi = nullptr) {
   const QgGeom &g = c->g;
   QgDstParams D;
   memset(&D, 0, sizeof(D));
@@ -856,6 +856,8 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
   P.ochom = c->ochom;
   P.pnew = c->p[c->ip ^ 1];
   P.sc = c->sc;
+  P.msg_lo = msg_lo;
+  P.msg_hi = msg_hi;
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
   QgBdyParams B;
   fill_bdy_params(c, B);
@@ -1376,12 +1378,13 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
       if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
       if (qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
       if (can_fuse_dst_unpack(c)) {
-        if (launch_dst_unpack(c, true)) return 1;
+        // the fused kernel also writes the halo messages (first / last three owned rows of po, edge row of qo)
+        if (launch_dst_unpack(c, true, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr)) return 1;
         c->ip ^= 1;
-      } else {
-        if (qgcm_hip_row_transform(c, 1)) return 1;
-        if (qgcm_hip_unpack(c, 1)) return 1;
+        return 0;
       }
+      if (qgcm_hip_row_transform(c, 1)) return 1;
+      if (qgcm_hip_unpack(c, 1)) return 1;
       if (nranks > 1) return qgcm_hip_halo_pack(c, b, cc);
       return 0;
     case 3:
