@@ -487,6 +487,48 @@ def test_library_issued_exchanges_one_rank(graph, monkeypatch):
         o.close()
 
 
+def test_bench_n8_workload_as_virtual_ranks():
+    """Exactly the decomposition bench.py --gpus 8 runs (weak scaling: a 961 x 7681 x 3 basin, eight
+    NAtl-5km-shaped slabs), here with the eight slabs as virtual ranks on this one GPU; three steps against the
+    single-domain CPU oracle.  Only the transport differs from the real 8-GPU run."""
+    import dataclasses
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg5 = preset("natl5")
+    nranks = 8
+    cfg = dataclasses.replace(cfg5, name="natl5_x8", nyaooc=cfg5.nyaooc * nranks, nyta=cfg5.nyta * nranks)
+    o = make_oracle(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))
+        po = synth.gaussian_eddy(cfg, noise=1e-3)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        zero2 = np.zeros((cfg.nxpo, cfg.nypo), order="F")
+        qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+        scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+        o.set_p(po, po)
+        o.set_forcing(wek, zero2, np.zeros(cfg.nlo - 1))
+        parts = partition(cfg.nypo, nranks)
+        assert all(abs((g1 - g0 + 1) - 960) <= 1 for g0, g1 in parts)
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.scatter_state(po, po, qo, qo, wek, zero2, np.zeros(cfg.nlo - 1), scal)
+        so.steps(3, s0=1)
+        o.steps(1, 3)
+        ref = o.get_state()
+        for g0, g1, fields in so.gather_local():
+            for f, x, y in zip(FIELDS, fields, ref):
+                assert relerr(x, y[:, g0 - 1:g1, :]) < 1e-11, (f, g0)
+        for sl in slabs:
+            assert np.array_equal(sl.get_scalars(), slabs[0].get_scalars())
+    finally:
+        for sl in slabs:
+            sl.close()
+        o.close()
+
+
 def test_full_size_natl1_slabs_vs_oracle():
     """BASELINE configs[4]: NAtl 1 km (4801 x 4801 x 3) as y-slabs.  Four slabs run as
     virtual ranks on this one GPU (the 8-GPU run only changes the transport); two
