@@ -7,7 +7,7 @@
 //
 // Here one workgroup transforms TWO rows at once: the two pre-twiddled real
 // sequences of length N = n+1 = nxto are packed as real/imaginary parts of one
-// complex sequence, a Stockham mixed-radix (2,3,4,5) complex FFT of length N
+// complex sequence, a Stockham mixed-radix (8,4,2,3,5) complex FFT of length N
 // runs in LDS, the two real spectra are separated by conjugate symmetry and
 // the FFTPACK post-process (including its running sum, done as a block scan)
 // produces both sine transforms.  The transform is its own inverse up to
@@ -27,6 +27,28 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - 
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 // multiply by -i (forward quarter turn)
 __device__ __forceinline__ cplx cmni(cplx a) { return {a.y, -a.x}; }
+
+// forward 8-point DFT, y[c] = sum_a x[a] exp(-2 pi i a c / 8), in place (radix-8 stage of the generic plan)
+__device__ __forceinline__ void dft8_g(cplx *x) {
+  const double r2 = 0.70710678118654752440;
+  cplx e0 = cadd(x[0], x[4]), o0 = csub(x[0], x[4]);
+  cplx e1 = cadd(x[1], x[5]), o1 = csub(x[1], x[5]);
+  cplx e2 = cadd(x[2], x[6]), o2 = csub(x[2], x[6]);
+  cplx e3 = cadd(x[3], x[7]), o3 = csub(x[3], x[7]);
+  cplx p1 = {r2 * (o1.x + o1.y), r2 * (o1.y - o1.x)};   // o1 * (1 - i)/sqrt2
+  cplx p2 = cmni(o2);                                   // o2 * (-i)
+  cplx p3 = {r2 * (o3.y - o3.x), -r2 * (o3.x + o3.y)};  // o3 * (-1 - i)/sqrt2
+  cplx t0 = cadd(e0, e2), t1 = csub(e0, e2), t2 = cadd(e1, e3), t3 = cmni(csub(e1, e3));
+  x[0] = cadd(t0, t2);
+  x[4] = csub(t0, t2);
+  x[2] = cadd(t1, t3);
+  x[6] = csub(t1, t3);
+  cplx u0 = cadd(o0, p2), u1 = csub(o0, p2), u2 = cadd(p1, p3), u3 = cmni(csub(p1, p3));
+  x[1] = cadd(u0, u2);
+  x[5] = csub(u0, u2);
+  x[3] = cadd(u1, u3);
+  x[7] = csub(u1, u3);
+}
 
 // One Stockham DIF stage of radix R over the whole length-N sequence:
 //   a_r = in[q + s*(p + m*r)],  b_u = sum_r a_r w_R^{ru},  out[q + s*(R*p + u)] = b_u * w_len^{p*u}
@@ -50,6 +72,10 @@ __device__ __forceinline__ void dst_stage(const cplx *__restrict__ in, cplx *__r
       o[2] = csub(t0, t2);
       o[1] = cadd(t1, t3);
       o[3] = csub(t1, t3);
+    } else if (R == 8) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = a[r];
+      dft8_g(o);
     } else if (R == 3) {
       const double s3 = 0.86602540378443864676;
       cplx t1 = cadd(a[1], a[2]);
@@ -152,6 +178,7 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
       case 3: dst_stage<3>(in, out, N, s, mm, P.twid, twstep, tid); break;
       case 4: dst_stage<4>(in, out, N, s, mm, P.twid, twstep, tid); break;
       case 5: dst_stage<5>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 8: dst_stage<8>(in, out, N, s, mm, P.twid, twstep, tid); break;
       default: dst_stage_generic(R, in, out, N, s, mm, P.twid, twstep, tid); break;
     }
     __syncthreads();
@@ -311,6 +338,7 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
       case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
       case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
       case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 8: dst_stage<8, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
       default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
     }
     __syncthreads();

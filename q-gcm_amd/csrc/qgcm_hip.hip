@@ -107,8 +107,8 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static int factorize(int n, int *fac) {
   int nf = 0;
-  static const int tr[4] = {4, 2, 3, 5};
-  for (int t = 0; t < 4; ++t)
+  static const int tr[5] = {8, 4, 2, 3, 5}; // fewest passes through LDS (FFTPACK's own order is 4,2,3,5)
+  for (int t = 0; t < 5; ++t)
     while (n % tr[t] == 0) {
       fac[nf++] = tr[t];
       n /= tr[t];
