@@ -18,6 +18,8 @@
 #include "qgcm_dev.h"
 
 #define DST_NT 128
+#define DST_NT_BIG 512
+#define DST_BIG_N 2048 // rows at least this long use DST_NT_BIG threads
 
 struct cplx {
   double x, y;
@@ -131,14 +133,15 @@ __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict_
 }
 
 // grid: (ceil(nrows/2), nlayers);  rows j = jr0..jr1 (owned, interior to the global domain)
-// dynamic LDS: 2*N cplx + 2*DST_NT doubles
-template <bool ROWSUM>
-__global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
+// dynamic LDS: 2*N cplx + 2*NT doubles; NT = 128 threads for short rows, DST_NT_BIG for long ones (a long row
+// fills the LDS of a CU by itself, so the one resident workgroup must bring enough waves)
+template <bool ROWSUM, int NT = DST_NT>
+__global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = P.N, n = N - 1;
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
   cplx *B = A + N;
-  double *red = reinterpret_cast<double *>(B + N); // 2*DST_NT doubles
+  double *red = reinterpret_cast<double *>(B + N); // 2*NT doubles
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y + P.layer0;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
   // ---- pre-twiddle (dsint.f:19-33): element a[k], k=1..n lives at index k-1
   const int ns2 = n / 2;
   if (tid == 0) A[0] = {0.0, 0.0};
-  for (int k = 1 + tid; k <= ns2; k += DST_NT) {
+  for (int k = 1 + tid; k <= ns2; k += NT) {
     double xa = rowa[k - 1], xac = rowa[n - k];
     double xb = has_b ? rowb[k - 1] : 0.0, xbc = has_b ? rowb[n - k] : 0.0;
     double sn = P.sintab[k];
@@ -174,12 +177,12 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
     const int mm = len / R;
     const int twstep = N / len;
     switch (R) {
-      case 2: dst_stage<2>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 3: dst_stage<3>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 4: dst_stage<4>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 5: dst_stage<5>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 8: dst_stage<8>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      default: dst_stage_generic(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 2: dst_stage<2, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      case 8: dst_stage<8, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+      default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
     }
     __syncthreads();
     cplx *t = in;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
   //   Y'_k = (Z_k - conj Z_{N-k})/(2i)   (row b)
   //   b[1] = 0.5 Re Y_0 ; b[2k] = -Im Y_k ; b[2k+1] = b[2k-1] + Re Y_k
   const int K = (n - 1) / 2;              // odd outputs b[2k+1], k=1..K
-  const int chunk = (K + DST_NT - 1) / DST_NT;
+  const int chunk = (K + NT - 1) / NT;
   const int k0 = 1 + tid * chunk;
   double suma = 0.0, sumb = 0.0;
   for (int k = k0; k < k0 + chunk && k <= K; ++k) {
@@ -204,25 +207,25 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
     sumb += 0.5 * (z1.y + z2.y);
   }
   red[tid] = suma;
-  red[DST_NT + tid] = sumb;
+  red[NT + tid] = sumb;
   __syncthreads();
-  // inclusive Hillis-Steele scan over the DST_NT partials (both rows)
-  for (int off = 1; off < DST_NT; off <<= 1) {
+  // inclusive Hillis-Steele scan over the NT partials (both rows)
+  for (int off = 1; off < NT; off <<= 1) {
     double va = 0.0, vb = 0.0;
     if (tid >= off) {
       va = red[tid - off];
-      vb = red[DST_NT + tid - off];
+      vb = red[NT + tid - off];
     }
     __syncthreads();
     if (tid >= off) {
       red[tid] += va;
-      red[DST_NT + tid] += vb;
+      red[NT + tid] += vb;
     }
     __syncthreads();
   }
   const double b1a = 0.5 * Z[0].x, b1b = 0.5 * Z[0].y;
   double runa = b1a + (tid > 0 ? red[tid - 1] : 0.0);
-  double runb = b1b + (tid > 0 ? red[DST_NT + tid - 1] : 0.0);
+  double runb = b1b + (tid > 0 ? red[NT + tid - 1] : 0.0);
   double rsa = 0.0, rsb = 0.0; // row sums (inverse pass: area integral, intsubs.f:78-133)
   if (tid == 0) {
     rowa[0] = b1a;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
     }
   }
   // n even: the last even output b[n] = -Im Y_{n/2} has no odd partner
-  if (!(n & 1) && tid == DST_NT - 1) {
+  if (!(n & 1) && tid == NT - 1) {
     int k = n / 2;
     cplx z1 = Z[k], z2 = Z[N - k];
     double ima = 0.5 * (z1.y - z2.y), imb = -0.5 * (z1.x - z2.x);
@@ -260,18 +263,18 @@ __global__ __launch_bounds__(DST_NT) void k_dst_box(const QgDstParams P) {
   if (ROWSUM) {
     __syncthreads();
     red[tid] = rsa;
-    red[DST_NT + tid] = rsb;
+    red[NT + tid] = rsb;
     __syncthreads();
-    for (int off = DST_NT / 2; off > 0; off >>= 1) {
+    for (int off = NT / 2; off > 0; off >>= 1) {
       if (tid < off) {
         red[tid] += red[tid + off];
-        red[DST_NT + tid] += red[DST_NT + tid + off];
+        red[NT + tid] += red[NT + tid + off];
       }
       __syncthreads();
     }
     if (tid == 0) {
       P.rowsum[(long)m * ny + (ja - 1)] = red[0];
-      if (has_b) P.rowsum[(long)m * ny + ja] = red[DST_NT];
+      if (has_b) P.rowsum[(long)m * ny + ja] = red[NT];
     }
   }
 }

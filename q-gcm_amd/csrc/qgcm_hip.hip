@@ -353,10 +353,11 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipMalloc((void **)&c->sintab, sizeof(double) * st.size()));
   HIPCHECK(hipMemcpy(c->twid, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(c->sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
-  c->dst_lds = (size_t)2 * N * sizeof(cplx) + 2 * (g.cyc ? RFFT_NT : DST_NT) * sizeof(double);
+  c->dst_lds = (size_t)2 * N * sizeof(cplx) + 2 * (g.cyc ? RFFT_NT : (N >= DST_BIG_N ? DST_NT_BIG : DST_NT)) * sizeof(double);
   if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
+  HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false, DST_NT_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   c->grid_set = true;
@@ -689,7 +690,8 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
     hipLaunchKernelGGL((k_dst64<15, false>), grid64, dim3(D64_NT), 0, st, P);
   } else if (c->fftN == 64 * 3 && !c->force_generic_dst) {
     hipLaunchKernelGGL((k_dst64<3, false>), grid64, dim3(D64_NT), 0, st, P);
-  } else hipLaunchKernelGGL((k_dst_box<false>), grid, dim3(DST_NT), c->dst_lds, st, P);
+  } else if (c->fftN >= DST_BIG_N) hipLaunchKernelGGL((k_dst_box<false, DST_NT_BIG>), grid, dim3(DST_NT_BIG), c->dst_lds, st, P);
+  else hipLaunchKernelGGL((k_dst_box<false>), grid, dim3(DST_NT), c->dst_lds, st, P);
   HIPCHECK(hipGetLastError());
   return 0;
 }
