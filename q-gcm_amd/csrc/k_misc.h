@@ -51,12 +51,24 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
 #pragma unroll
   for (int m = 0; m < NL; ++m) s[m] = 0.0;
   // area integrals from the spectral column sums: xintp(wrk_m) = sum_k wcot(k) * ksum(m,k)
-  // (k_thomas.h); only odd wavenumbers (even 0-based index) contribute
-  for (int k = 2 * lane; k < P.g.nk; k += 128) {
-    const double wk = P.wcot[k];
+  // (k_thomas.h); only odd wavenumbers (even 0-based index) contribute. Four independent partial sums per lane
+  // keep four loads in flight (2400 terms per mode at 1 km); the order is fixed: (s0 + s1) + (s2 + s3).
+  double s4[4][NL];
 #pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += wk * P.ksum[(long)m * P.g.ldw + k];
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int m = 0; m < NL; ++m) s4[u][m] = 0.0;
+  for (int k0 = 2 * lane; k0 < P.g.nk; k0 += 512) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 128 * u;
+      const double wk = k < P.g.nk ? P.wcot[k] : 0.0;
+#pragma unroll
+      for (int m = 0; m < NL; ++m) s4[u][m] += wk * (k < P.g.nk ? P.ksum[(long)m * P.g.ldw + k] : 0.0);
+    }
   }
+#pragma unroll
+  for (int m = 0; m < NL; ++m) s[m] = (s4[0][m] + s4[1][m]) + (s4[2][m] + s4[3][m]);
   // fixed-order butterfly: every lane ends with the same total
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -274,7 +274,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
 
 static int thomas_rows_per_chunk(int nrows) {
   const int need = (nrows + TH_NC - 1) / TH_NC;
-  for (int r : {1, 2, 4, 8, 16, 32})
+  for (int r : {1, 2, 4, 8, 10, 12, 16, 20, 24, 32}) // rows per thread; 10 / 20: the 600- and 1200-row slabs of NAtl 1 km
     if (need <= r) return r;
   return -1;
 }
@@ -729,7 +729,11 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
     case 2: QG_TH(2); break;
     case 4: QG_TH(4); break;
     case 8: QG_TH(8); break;
+    case 10: QG_TH(10); break;
+    case 12: QG_TH(12); break;
     case 16: QG_TH(16); break;
+    case 20: QG_TH(20); break;
+    case 24: QG_TH(24); break;
     case 32: QG_TH(32); break;
     default: QG_FAIL("k_thomas: too many rows for the single-segment kernel");
   }
