@@ -375,9 +375,9 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
 // new po - the transformed field never goes to HBM (saves 2 passes over wrk and a launch).
 // The workgroups of the first / last interior row also write the wall rows (G = 1, nyg).
 // Reference: src/ocisubs.F:494-499 (inverse dsint), 377-401 (unpack), src/vorsubs.F:245-388.
-// grid: (npairs), block 64*NL.
+// grid: (npairs), block 64*NL.  HALO: also write the y-slab halo messages (whole-domain handles compile it out).
 // ---------------------------------------------------------------------------
-template <int M, int NL, bool BDY>
+template <int M, int NL, bool BDY, bool HALO>
 __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, const QgUnpackParams U, const QgBdyParams B) {
   constexpr int N = 64 * M, NP = N + N / 16;
   __shared__ __align__(16) cplx Fsh[NL][M * D64_ROW];
@@ -433,18 +433,18 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
   // owned rows go to the lower / upper neighbour straight from here (no separate pack launch)
   const int jlo = U.g.jlo, jhi = U.g.jhi, ldxm = U.g.ldx;
   auto msg_p = [&](int gi, int gj, const double *pl) {
-    if (U.msg_lo && gj - jlo < 3) {
+    if (HALO && U.msg_lo && gj - jlo < 3) {
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.msg_lo[((long)k * 3 + (gj - jlo)) * ldxm + (gi - 1)] = pl[k];
     }
-    if (U.msg_hi && jhi - gj < 3) {
+    if (HALO && U.msg_hi && jhi - gj < 3) {
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.msg_hi[((long)k * 3 + (gj - (jhi - 2))) * ldxm + (gi - 1)] = pl[k];
     }
   };
   auto msg_q = [&](int gi, int gj, int k, double q) {
-    if (U.msg_lo && gj == jlo) U.msg_lo[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
-    if (U.msg_hi && gj == jhi) U.msg_hi[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
+    if (HALO && U.msg_lo && gj == jlo) U.msg_lo[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
+    if (HALO && U.msg_hi && gj == jhi) U.msg_hi[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
   };
   // unpack_point of k_misc.h with the transformed rows taken from LDS; sel: 0 row a, 1 row b, -1 wall row;
   // ocv: prefetched ochom values of the point, or nullptr (read them here)
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
       msg_p(gi, gj, pl);
-      if ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi)) { // interior columns of the q row: set by k_tend
+      if (HALO && ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi))) { // interior columns of the q row: set by k_tend
 #pragma unroll
         for (int k = 0; k < NL; ++k) msg_q(gi, gj, k, B.qo[fs * k + o]);
       }

@@ -870,9 +870,10 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nu
   const int nrows = g.jr1 - g.jr0 + 1;
   dim3 grid((nrows + 1) / 2);
   KTimer t(c, KN_DSTI);
-#define QG_DU(MV, NLV)                                                                                          \
-  if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true>), grid, dim3(64 * NLV), 0, c->stream, D, P, B); \
-  else hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B)
+#define QG_DU(MV, NLV)                                                                                                  \
+  if (msg_lo || msg_hi) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true>), grid, dim3(64 * NLV), 0, c->stream, D, P, B); \
+  else if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B);  \
+  else hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B)
 #define QG_DU_NL(MV)                 \
   switch (g.nl) {                    \
     case 2: QG_DU(MV, 2); break;     \
