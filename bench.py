@@ -182,11 +182,65 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         (_, _, fields), = so.gather_local()
         return fields + [slab.get_scalars()]
 
-    # The exchanges are issued either by Python (torch.distributed between the four stage calls) or by the
-    # library itself (qgcm_hip_slab_steps: RCCL calls from C++ on the same stream).  The second keeps the host out
-    # of the step loop; it is used when its results are bitwise those of the first on every rank.
-    driver = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
-    if os.environ.get("QGCM_BENCH_EXCHANGES", "library") == "library" and dist.get_backend() == "nccl":
+    def measure():
+        """warm-up + exactly args.steps timed steps with the current driver; max over ranks; state check"""
+        so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
+        so.steps(args.warmup, s0=1)
+        barrier()
+        t0 = time.perf_counter()
+        so.steps(args.steps, s0=args.warmup + 1)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        (_, _, fields), = so.gather_local()
+        fin = torch.tensor([1.0 if all(np.isfinite(x).all() for x in fields) else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+        return float(t.item()), bool(fin.item() > 0.5)
+
+    def line(wall, finite, driver):
+        basin_sps = args.steps / wall
+        npts = cfg5.nxpo * cfg5.nypo
+        return json.dumps({
+            "metric": "ocean timesteps/sec (NAtl 5km 3-layer qgostep+ocinvq+ocqbdy)",
+            "value": round(world * basin_sps, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "NAtl 5km-shaped slab per GPU: 961 x %d x 3 basin (%d x taller), dto=540s, "
+                                   "Gaussian-eddy IC + double-gyre wind, oml off" % (cfg.nypo, world),
+                       "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
+                       "parallelism": "y-slabs over %d GPUs: two exchanges per step - one all-gather of the slab summaries "
+                                      "(tridiagonal sweeps + area integrals) and one of the halo rows (RCCL)" % world,
+                       "exchange_driver": driver,
+                       "value_counts": "NAtl-5km-equivalent timesteps = n_gpus x basin timesteps"},
+            "basin_steps_per_s": round(basin_sps, 2),
+            "model_years_per_day": round(cfg5.model_years_per_day(basin_sps), 1),
+            "state_finite": finite,
+            "step_hbm_frac_per_gpu": round(56 * npts * 8.0 * basin_sps / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": None, "cpu_baseline": None,
+        }) + "\n"
+
+    # 1. The exchanges issued by Python (torch.distributed between the three stage calls): the plain, safe driver.
+    #    Its measurement is kept as the line to print should anything below fail or stall.
+    drv_torch = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
+    wall_t, fin_t = measure()
+    best = (wall_t, fin_t, drv_torch)
+    use_library = os.environ.get("QGCM_BENCH_EXCHANGES", "library") == "library" and dist.get_backend() == "nccl"
+    if use_library:
+        # 2. The exchanges issued by the library itself (qgcm_hip_slab_steps: RCCL from C++ on the same stream, the
+        #    host out of the step loop). This path cannot be exercised on the one-GPU development box beyond a
+        #    one-rank communicator, so it runs under a watchdog: if it stalls, every rank leaves and rank 0 prints
+        #    the torch.distributed line measured above.
+        import threading
+
+        def bail():
+            if rank == 0:
+                real_stdout.write(line(*best))
+                real_stdout.flush()
+            print("bench.py: library-issued exchanges stalled; reported the torch.distributed measurement", file=sys.stderr)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("QGCM_BENCH_WATCHDOG_S", "240")), bail)
+        dog.daemon = True
+        dog.start()
         nver = 7
         so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
         so.steps(nver, s0=1)
@@ -196,8 +250,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         try:
             so.use_library_exchanges(broadcast_unique_id(dist, slab.device))
             so.steps(nver, s0=1)
-            got = local_state()
-            ok = 1.0 if all(np.array_equal(a, b) for a, b in zip(ref, got)) else 0.0
+            ok = 1.0 if all(np.array_equal(a, b) for a, b in zip(ref, local_state())) else 0.0
         except Exception as e:  # noqa: BLE001 - any failure means: stay with the torch.distributed driver
             print("library-issued exchanges unavailable: %r" % (e,), file=sys.stderr)
             ok = 0.0
@@ -205,6 +258,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if t.item() > 0.5:
             driver = "library-issued RCCL (qgcm_hip_slab_steps), verified bitwise against the torch.distributed driver"
+
             # transport of the halo rows: one all-gather of everybody's edge rows, or grouped send/recv with the
             # two neighbours - measured on this node (max over ranks), the faster one is used if it is also bitwise
             def timed(p2p):
@@ -230,45 +284,16 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             except Exception as e:  # noqa: BLE001
                 print("halo transport tuning failed: %r" % (e,), file=sys.stderr)
                 slab.set_halo_p2p(False)
-        else:
-            so.native = False
-    so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
-    so.steps(args.warmup, s0=1)
-    barrier()
-    t0 = time.perf_counter()
-    so.steps(args.steps, s0=args.warmup + 1)
-    barrier()
-    wall = time.perf_counter() - t0
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
-    (_, _, fields), = so.gather_local()
-    fin = torch.tensor([1.0 if all(np.isfinite(x).all() for x in fields) else 0.0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+            wall_l, fin_l = measure()
+            driver += "; torch.distributed driver: %.1f us/step" % (1e6 * wall_t / args.steps)
+            if fin_l and wall_l <= wall_t:
+                best = (wall_l, fin_l, driver)
+            else:
+                best = (wall_t, fin_t, drv_torch + "; library-issued driver: %.1f us/step" % (1e6 * wall_l / args.steps))
+        dog.cancel()
     dist.barrier()
     if rank == 0:
-        basin_sps = args.steps / wall
-        value = world * basin_sps
-        npts = cfg5.nxpo * cfg5.nypo
-        out = {
-            "metric": "ocean timesteps/sec (NAtl 5km 3-layer qgostep+ocinvq+ocqbdy)",
-            "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "NAtl 5km-shaped slab per GPU: 961 x %d x 3 basin (%d x taller), dto=540s, "
-                                   "Gaussian-eddy IC + double-gyre wind, oml off" % (cfg.nypo, world),
-                       "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
-                       "parallelism": "y-slabs over %d GPUs: two exchanges per step - one all-gather of the slab summaries "
-                                      "(tridiagonal sweeps + area integrals) and one of the halo rows (RCCL)" % world,
-                       "exchange_driver": driver,
-                       "value_counts": "NAtl-5km-equivalent timesteps = n_gpus x basin timesteps"},
-            "basin_steps_per_s": round(basin_sps, 2),
-            "model_years_per_day": round(cfg5.model_years_per_day(basin_sps), 1),
-            "state_finite": bool(fin.item() > 0.5),
-            "step_hbm_frac_per_gpu": round(56 * npts * 8.0 * basin_sps / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": None, "cpu_baseline": None,
-        }
-        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.write(line(*best))
         real_stdout.flush()
     dist.destroy_process_group()
 
