@@ -192,6 +192,10 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     len = mm;
   }
   const cplx *Z = in;
+  // the other buffer is free now: the output rows are staged there (row a: oa[0..n-1], row b: ob[0..n-1]) and
+  // written to global memory in one coalesced sweep (each thread produces runs of consecutive elements, which
+  // would otherwise go out as short strided stores)
+  double *oa = reinterpret_cast<double *>(out), *ob = oa + N;
 
   // ---- separate the two real spectra and post-process (dsint.f:37-44) ----
   //   Y_k  = (Z_k + conj Z_{N-k})/2      (row a)
@@ -228,8 +232,8 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   double runb = b1b + (tid > 0 ? red[NT + tid - 1] : 0.0);
   double rsa = 0.0, rsb = 0.0; // row sums (inverse pass: area integral, intsubs.f:78-133)
   if (tid == 0) {
-    rowa[0] = b1a;
-    if (has_b) rowb[0] = b1b;
+    oa[0] = b1a;
+    ob[0] = b1b;
     rsa += b1a;
     rsb += b1b;
   }
@@ -239,26 +243,27 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     double reb = 0.5 * (z1.y + z2.y), imb = -0.5 * (z1.x - z2.x);
     runa += rea;
     runb += reb;
-    rowa[2 * k - 1] = -ima; // b[2k]
-    rowa[2 * k] = runa;     // b[2k+1]
+    oa[2 * k - 1] = -ima; // b[2k]
+    oa[2 * k] = runa;     // b[2k+1]
     rsa += runa - ima;
-    if (has_b) {
-      rowb[2 * k - 1] = -imb;
-      rowb[2 * k] = runb;
-      rsb += runb - imb;
-    }
+    ob[2 * k - 1] = -imb;
+    ob[2 * k] = runb;
+    if (has_b) rsb += runb - imb;
   }
   // n even: the last even output b[n] = -Im Y_{n/2} has no odd partner
   if (!(n & 1) && tid == NT - 1) {
     int k = n / 2;
     cplx z1 = Z[k], z2 = Z[N - k];
     double ima = 0.5 * (z1.y - z2.y), imb = -0.5 * (z1.x - z2.x);
-    rowa[n - 1] = -ima;
+    oa[n - 1] = -ima;
     rsa += -ima;
-    if (has_b) {
-      rowb[n - 1] = -imb;
-      rsb += -imb;
-    }
+    ob[n - 1] = -imb;
+    if (has_b) rsb += -imb;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) {
+    rowa[i] = oa[i];
+    if (has_b) rowb[i] = ob[i];
   }
   if (ROWSUM) {
     __syncthreads();
