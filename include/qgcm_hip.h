@@ -121,7 +121,7 @@ int qgcm_hip_get_inv_diag(qgcm_hip_handle h, double *xinhom, double *coef);
 int qgcm_hip_qgostep(qgcm_hip_handle h);    /* replaces "call qgostep"        q-gcm.F:1243 */
 int qgcm_hip_ocinvq(qgcm_hip_handle h);     /* replaces "call ocinvq"         q-gcm.F:1246 */
 int qgcm_hip_ocqbdy(qgcm_hip_handle h);     /* replaces "call ocqbdy (qo,po)" q-gcm.F:1249 */
-int qgcm_hip_lf_average(qgcm_hip_handle h); /* ocean part of q-gcm.F:1328-1366 */
+int qgcm_hip_lf_average(qgcm_hip_handle h); /* ocean part of q-gcm.F:1328-1366 (incl. sst once qgcm_hip_oml_init was called) */
 /* n whole ocean steps starting at 1-based ocean step index s0: qgostep, ocinvq,
  * ocqbdy and, when mod(s-1,25)==0, the averaging (nt = 1+(s-1)*nstr in
  * q-gcm.F:1222,1328).  Uses captured HIP graphs. */

@@ -985,9 +985,15 @@ extern "C" int qgcm_hip_ocqbdy(qgcm_hip_handle c) {
   return launch_ocqbdy(c);
 }
 
+static int launch_oml_average(qgcm_hip_ctx *c);
+
+// the whole ocean part of the averaging block src/q-gcm.F:1328-1366: po, qo, constraint scalars and - when the
+// mixed layer lives on the device - sst
 extern "C" int qgcm_hip_lf_average(qgcm_hip_handle c) {
   if (check_ready(c, "qgcm_hip_lf_average")) return 1;
-  return launch_lfavg(c);
+  if (launch_lfavg(c)) return 1;
+  if (c->oml.on && launch_oml_average(c)) return 1;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1197,8 +1203,7 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   if (qgcm_hip_qgostep(c)) return 1;
   if (ocinvq_impl(c, true)) return 1; // ocqbdy fused into the unpack kernel
   if ((s - 1) % 25 == 0) {
-    if (qgcm_hip_lf_average(c)) return 1;
-    if (c->oml.on && launch_oml_average(c)) return 1;
+    if (qgcm_hip_lf_average(c)) return 1; // incl. sst when the mixed layer is on
   }
   if (c->profiling) {
     // an empty launch bracketed like the kernels (see qgcm_hip_profile_steps)

@@ -102,6 +102,29 @@ def test_graph_replay_and_oracle(cfgname, sb, nb):
         o.close()
 
 
+def test_one_for_one_calls_equal_steps():
+    """The call sequence of the reference main program issued call by call (oml, qgostep, ocinvq, ocqbdy and the
+    averaging block when mod(s-1,25) == 0 - as the Fortran shim does) is bitwise qgcm_hip_steps."""
+    g, cfg = load_golden("oml_box_tiny"), preset("box_tiny")
+    om = oml_config(g)
+    ma, mb = OceanModel(cfg), OceanModel(cfg)
+    try:
+        for m in (ma, mb):
+            m.oml_init(om)
+            oml_load(m, g, cfg, False)
+        ma.steps(30, s0=1)
+        for s in range(1, 31):
+            mb.oml(); mb.qgostep(); mb.ocinvq(); mb.ocqbdy()
+            if (s - 1) % 25 == 0:
+                mb.lf_average()
+        for x, y in zip(ma.get_state() + ma.oml_get_state(), mb.get_state() + mb.oml_get_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(ma.get_scalars(), mb.get_scalars())
+    finally:
+        ma.close()
+        mb.close()
+
+
 def test_oml_needs_init_and_whole_domain():
     cfg = preset("box_small")
     m = OceanModel(cfg)
