@@ -20,6 +20,10 @@
 #define DST_NT 128
 #define DST_NT_BIG 512
 #define DST_BIG_N 2048 // rows at least this long use DST_NT_BIG threads
+// single-buffer (in-place) stages for rows whose two ping-pong buffers would not let two workgroups share a CU:
+// 2*N*16 B > 80 KB, N*16 B + 256 B <= 80 KB, and N / (R * 512) within the MAXIT bounds of the kernels
+#define DST_SINGLE_MINN 2561
+#define DST_SINGLE_MAXN 5104
 
 struct cplx {
   double x, y;
@@ -52,6 +56,50 @@ __device__ __forceinline__ void dft8_g(cplx *x) {
   x[7] = csub(u1, u3);
 }
 
+// radix-R butterfly: o[u] = sum_r a[r] exp(-2 pi i r u / R)
+template <int R>
+__device__ __forceinline__ void dst_bfly(const cplx *a, cplx *o) {
+  if (R == 2) {
+    o[0] = cadd(a[0], a[1]);
+    o[1] = csub(a[0], a[1]);
+  } else if (R == 4) {
+    cplx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+    cplx t2 = cadd(a[1], a[3]), t3 = cmni(csub(a[1], a[3]));
+    o[0] = cadd(t0, t2);
+    o[2] = csub(t0, t2);
+    o[1] = cadd(t1, t3);
+    o[3] = csub(t1, t3);
+  } else if (R == 8) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = a[r];
+    dft8_g(o);
+  } else if (R == 3) {
+    const double s3 = 0.86602540378443864676;
+    cplx t1 = cadd(a[1], a[2]);
+    cplx t2 = {a[0].x - 0.5 * t1.x, a[0].y - 0.5 * t1.y};
+    cplx d = csub(a[1], a[2]);
+    cplx t3 = {s3 * d.y, -s3 * d.x}; // -i * s3 * d
+    o[0] = cadd(a[0], t1);
+    o[1] = cadd(t2, t3);
+    o[2] = csub(t2, t3);
+  } else if (R == 5) {
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+    cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
+    cplx t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+    o[0] = {a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y};
+    cplx m1 = {a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y};
+    cplx m2 = {a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y};
+    // -i*(s1*t3 + s2*t4), -i*(s2*t3 - s1*t4)
+    cplx n1 = {s1 * t3.y + s2 * t4.y, -(s1 * t3.x + s2 * t4.x)};
+    cplx n2 = {s2 * t3.y - s1 * t4.y, -(s2 * t3.x - s1 * t4.x)};
+    o[1] = cadd(m1, n1);
+    o[4] = csub(m1, n1);
+    o[2] = cadd(m2, n2);
+    o[3] = csub(m2, n2);
+  }
+}
+
 // One Stockham DIF stage of radix R over the whole length-N sequence:
 //   a_r = in[q + s*(p + m*r)],  b_u = sum_r a_r w_R^{ru},  out[q + s*(R*p + u)] = b_u * w_len^{p*u}
 template <int R, int NT = DST_NT>
@@ -64,50 +112,49 @@ __device__ __forceinline__ void dst_stage(const cplx *__restrict__ in, cplx *__r
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = in[q + s * (p + m * r)];
     cplx o[R];
-    if (R == 2) {
-      o[0] = cadd(a[0], a[1]);
-      o[1] = csub(a[0], a[1]);
-    } else if (R == 4) {
-      cplx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
-      cplx t2 = cadd(a[1], a[3]), t3 = cmni(csub(a[1], a[3]));
-      o[0] = cadd(t0, t2);
-      o[2] = csub(t0, t2);
-      o[1] = cadd(t1, t3);
-      o[3] = csub(t1, t3);
-    } else if (R == 8) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = a[r];
-      dft8_g(o);
-    } else if (R == 3) {
-      const double s3 = 0.86602540378443864676;
-      cplx t1 = cadd(a[1], a[2]);
-      cplx t2 = {a[0].x - 0.5 * t1.x, a[0].y - 0.5 * t1.y};
-      cplx d = csub(a[1], a[2]);
-      cplx t3 = {s3 * d.y, -s3 * d.x}; // -i * s3 * d
-      o[0] = cadd(a[0], t1);
-      o[1] = cadd(t2, t3);
-      o[2] = csub(t2, t3);
-    } else if (R == 5) {
-      const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
-      const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
-      cplx t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
-      cplx t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
-      o[0] = {a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y};
-      cplx m1 = {a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y};
-      cplx m2 = {a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y};
-      // -i*(s1*t3 + s2*t4), -i*(s2*t3 - s1*t4)
-      cplx n1 = {s1 * t3.y + s2 * t4.y, -(s1 * t3.x + s2 * t4.x)};
-      cplx n2 = {s2 * t3.y - s1 * t4.y, -(s2 * t3.x - s1 * t4.x)};
-      o[1] = cadd(m1, n1);
-      o[4] = csub(m1, n1);
-      o[2] = cadd(m2, n2);
-      o[3] = csub(m2, n2);
-    }
+    dst_bfly<R>(a, o);
     out[q + s * (R * p)] = o[0];
 #pragma unroll
     for (int u = 1; u < R; ++u) {
       double2 w = tw[p * u * twstep];
       out[q + s * (R * p + u)] = cmul(o[u], cplx{w.x, w.y});
+    }
+  }
+}
+
+// The same stage IN PLACE (single LDS buffer): every thread first takes all its butterflies into registers, the
+// workgroup synchronises, then the results are written back. Costs one more barrier per stage and
+// MAXIT*R complex registers, halves the LDS footprint - a 4608- or 4800-point row pair then leaves room for a
+// second workgroup on the CU.  MAXIT >= ceil(N / (R * NT)).
+template <int R, int NT, int MAXIT>
+__device__ __forceinline__ void dst_stage_ip(cplx *__restrict__ buf, int N, int s, int m, const double2 *__restrict__ tw,
+                                             int twstep, int tid) {
+  const int nb = m * s;
+  cplx o[MAXIT][R];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int b = tid + it * NT;
+    if (b < nb) {
+      int p = b / s, q = b - p * s;
+      cplx a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = buf[q + s * (p + m * r)];
+      dst_bfly<R>(a, o[it]);
+#pragma unroll
+      for (int u = 1; u < R; ++u) {
+        double2 w = tw[p * u * twstep];
+        o[it][u] = cmul(o[it][u], cplx{w.x, w.y});
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int b = tid + it * NT;
+    if (b < nb) {
+      int p = b / s, q = b - p * s;
+#pragma unroll
+      for (int u = 0; u < R; ++u) buf[q + s * (R * p + u)] = o[it][u];
     }
   }
 }
@@ -302,9 +349,10 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
   constexpr int NT = RFFT_NT;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = P.N, H = N / 2;
+  const bool single = P.single != 0;
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
-  cplx *B = A + N;
-  double *red = reinterpret_cast<double *>(B + N);
+  cplx *B = single ? A : A + N;
+  double *red = reinterpret_cast<double *>((single ? A : B) + N); // 2 * (NT / 64) doubles
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y + P.layer0;
@@ -341,13 +389,23 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
     const int R = P.fac[f];
     const int mm = len / R;
     const int twstep = N / len;
-    switch (R) {
-      case 2: dst_stage<2, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 8: dst_stage<8, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+    if (single) { // N <= DST_SINGLE_MAXN: the MAXIT bounds below cover N / (R * NT)
+      switch (R) {
+        case 2: dst_stage_ip<2, NT, 5>(A, N, s, mm, P.twid, twstep, tid); break;
+        case 3: dst_stage_ip<3, NT, 4>(A, N, s, mm, P.twid, twstep, tid); break;
+        case 4: dst_stage_ip<4, NT, 3>(A, N, s, mm, P.twid, twstep, tid); break;
+        case 5: dst_stage_ip<5, NT, 2>(A, N, s, mm, P.twid, twstep, tid); break;
+        default: dst_stage_ip<8, NT, 2>(A, N, s, mm, P.twid, twstep, tid); break;
+      }
+    } else {
+      switch (R) {
+        case 2: dst_stage<2, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 8: dst_stage<8, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+      }
     }
     __syncthreads();
     cplx *t = in;
@@ -387,19 +445,26 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
       }
     }
     if (P.rowsum) {
-      red[tid] = rsa;
-      red[NT + tid] = rsb;
-      __syncthreads();
-      for (int off = NT / 2; off > 0; off >>= 1) {
-        if (tid < off) {
-          red[tid] += red[tid + off];
-          red[NT + tid] += red[NT + tid + off];
-        }
-        __syncthreads();
+      // fixed order: xor butterfly inside each wave, then the wave totals left to right
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        rsa += __shfl_xor(rsa, off);
+        rsb += __shfl_xor(rsb, off);
       }
+      __syncthreads(); // every thread is done with the spectrum in A (red may share its tail in single mode)
+      if ((tid & 63) == 0) {
+        red[tid >> 6] = rsa;
+        red[NT / 64 + (tid >> 6)] = rsb;
+      }
+      __syncthreads();
       if (tid == 0) {
-        P.rowsum[(long)m * ny + (ja - 1)] = red[0];
-        if (has_b) P.rowsum[(long)m * ny + ja] = red[NT];
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < NT / 64; ++w) {
+          ta += red[w];
+          tb += red[NT / 64 + w];
+        }
+        P.rowsum[(long)m * ny + (ja - 1)] = ta;
+        if (has_b) P.rowsum[(long)m * ny + ja] = tb;
       }
     }
   }

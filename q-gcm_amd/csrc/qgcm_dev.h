@@ -76,6 +76,7 @@ struct QgDstParams {
   int fac[QG_MAXFAC];
   int nlayers;            // layers to process (nl, or 1 for helmholtz())
   int layer0;             // first layer (mode) of this launch
+  int single;             // generic kernels: one LDS buffer, in-place stages (long rows: two workgroups per CU)
 };
 
 struct QgThomasParams {

@@ -66,6 +66,7 @@ struct qgcm_hip_ctx {
   QgConstr cs;
   bool grid_set, homog_set;
   bool whole; // the handle owns the whole domain (no y-slab neighbours)
+  bool dst_single = false; // generic row kernels run single-buffer (in-place) stages
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   std::vector<double> bd2oc;
@@ -353,7 +354,15 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipMalloc((void **)&c->sintab, sizeof(double) * st.size()));
   HIPCHECK(hipMemcpy(c->twid, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(c->sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
-  c->dst_lds = (size_t)2 * N * sizeof(cplx) + 2 * (g.cyc ? RFFT_NT : (N >= DST_BIG_N ? DST_NT_BIG : DST_NT)) * sizeof(double);
+  // generic row kernels: two ping-pong buffers, or ONE buffer with in-place stages for long rows (cyclic kernel)
+  c->dst_single = false;
+  if (g.cyc && N >= DST_SINGLE_MINN && N <= DST_SINGLE_MAXN && N % 2 == 0 && !getenv("QGCM_HIP_NO_SINGLE_BUFFER")) {
+    c->dst_single = true;
+    for (int f = 0; f < c->nfac; ++f)
+      if (c->fac[f] != 2 && c->fac[f] != 3 && c->fac[f] != 4 && c->fac[f] != 5 && c->fac[f] != 8) c->dst_single = false;
+  }
+  c->dst_lds = (size_t)(c->dst_single ? 1 : 2) * N * sizeof(cplx) + 2 * (g.cyc ? RFFT_NT : (N >= DST_BIG_N ? DST_NT_BIG : DST_NT)) * sizeof(double);
+  if (c->dst_single) c->dst_lds = (size_t)N * sizeof(cplx) + 2 * (RFFT_NT / 64) * sizeof(double);
   if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
@@ -674,6 +683,7 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   for (int f = 0; f < c->nfac; ++f) P.fac[f] = c->fac[f];
   P.nlayers = nlayers;
   P.layer0 = layer0;
+  P.single = c->dst_single ? 1 : 0;
   const int nrows = g.jr1 - g.jr0 + 1;
   const int npairs = (nrows + 1) / 2;
   dim3 grid(npairs, nlayers);
