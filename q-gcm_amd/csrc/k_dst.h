@@ -186,9 +186,10 @@ template <bool ROWSUM, int NT = DST_NT>
 __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = P.N, n = N - 1;
+  const bool single = P.single != 0; // one LDS buffer, in-place stages (N even, see DST_SINGLE_*)
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
-  cplx *B = A + N;
-  double *red = reinterpret_cast<double *>(B + N); // 2*NT doubles
+  cplx *B = single ? A : A + N;
+  double *red = reinterpret_cast<double *>((single ? A : B) + N); // 2 * (NT / 64) doubles
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y + P.layer0;
@@ -223,13 +224,23 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     const int R = P.fac[f];
     const int mm = len / R;
     const int twstep = N / len;
-    switch (R) {
-      case 2: dst_stage<2, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      case 8: dst_stage<8, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
-      default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+    if (single) { // NT = DST_NT_BIG here; the MAXIT bounds cover N / (R * NT) for N <= DST_SINGLE_MAXN
+      switch (R) {
+        case 2: dst_stage_ip<2, NT, 5>(A, N, s, mm, P.twid, twstep, tid); break;
+        case 3: dst_stage_ip<3, NT, 4>(A, N, s, mm, P.twid, twstep, tid); break;
+        case 4: dst_stage_ip<4, NT, 3>(A, N, s, mm, P.twid, twstep, tid); break;
+        case 5: dst_stage_ip<5, NT, 2>(A, N, s, mm, P.twid, twstep, tid); break;
+        default: dst_stage_ip<8, NT, 2>(A, N, s, mm, P.twid, twstep, tid); break;
+      }
+    } else {
+      switch (R) {
+        case 2: dst_stage<2, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 3: dst_stage<3, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 4: dst_stage<4, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 5: dst_stage<5, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        case 8: dst_stage<8, NT>(in, out, N, s, mm, P.twid, twstep, tid); break;
+        default: dst_stage_generic<NT>(R, in, out, N, s, mm, P.twid, twstep, tid); break;
+      }
     }
     __syncthreads();
     cplx *t = in;
@@ -238,11 +249,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     s *= R;
     len = mm;
   }
-  const cplx *Z = in;
-  // the other buffer is free now: the output rows are staged there (row a: oa[0..n-1], row b: ob[0..n-1]) and
-  // written to global memory in one coalesced sweep (each thread produces runs of consecutive elements, which
-  // would otherwise go out as short strided stores)
-  double *oa = reinterpret_cast<double *>(out), *ob = oa + N;
+  cplx *Z = single ? A : in;
 
   // ---- separate the two real spectra and post-process (dsint.f:37-44) ----
   //   Y_k  = (Z_k + conj Z_{N-k})/2      (row a)
@@ -251,36 +258,47 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   const int K = (n - 1) / 2;              // odd outputs b[2k+1], k=1..K
   const int chunk = (K + NT - 1) / NT;
   const int k0 = 1 + tid * chunk;
+  const double b1a = 0.5 * Z[0].x, b1b = 0.5 * Z[0].y; // read before anything is staged over the spectrum
   double suma = 0.0, sumb = 0.0;
   for (int k = k0; k < k0 + chunk && k <= K; ++k) {
     cplx z1 = Z[k], z2 = Z[N - k];
     suma += 0.5 * (z1.x + z2.x);
     sumb += 0.5 * (z1.y + z2.y);
   }
-  red[tid] = suma;
-  red[NT + tid] = sumb;
-  __syncthreads();
-  // inclusive Hillis-Steele scan over the NT partials (both rows)
-  for (int off = 1; off < NT; off <<= 1) {
-    double va = 0.0, vb = 0.0;
-    if (tid >= off) {
-      va = red[tid - off];
-      vb = red[NT + tid - off];
+  // exclusive prefix of the per-thread partial sums (FFTPACK's running sum): shuffles inside a wave, the wave
+  // totals through LDS
+  const int lane = tid & 63, wv = tid >> 6;
+  double inca = suma, incb = sumb;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    double va = __shfl_up(inca, off), vb = __shfl_up(incb, off);
+    if (lane >= off) {
+      inca += va;
+      incb += vb;
     }
-    __syncthreads();
-    if (tid >= off) {
-      red[tid] += va;
-      red[NT + tid] += vb;
-    }
-    __syncthreads();
   }
-  const double b1a = 0.5 * Z[0].x, b1b = 0.5 * Z[0].y;
-  double runa = b1a + (tid > 0 ? red[tid - 1] : 0.0);
-  double runb = b1b + (tid > 0 ? red[NT + tid - 1] : 0.0);
-  double rsa = 0.0, rsb = 0.0; // row sums (inverse pass: area integral, intsubs.f:78-133)
+  if (lane == 63) {
+    red[wv] = inca;
+    red[NT / 64 + wv] = incb;
+  }
+  __syncthreads();
+  double runa = b1a + (inca - suma), runb = b1b + (incb - sumb);
+  for (int w = 0; w < wv; ++w) {
+    runa += red[w];
+    runb += red[NT / 64 + w];
+  }
+  // Output staging for one coalesced sweep to global memory (each thread produces runs of consecutive elements):
+  //   two buffers : the free buffer, row a at oa[i], row b at ob[i]
+  //   one buffer  : in place - the four outputs of index k take the four doubles of Z[k], Z[N-k], which only this
+  //                 thread reads: row a: b[2k-1], b[2k] at A[k].x, A[k].y; row b at A[N-k].x, .y; b[0] at A[0]
+  double *oa = reinterpret_cast<double *>(out), *ob = oa + N;
+  double rsa = 0.0, rsb = 0.0; // row sums (inverse pass of the round-1a structure; kept for ROWSUM)
   if (tid == 0) {
-    oa[0] = b1a;
-    ob[0] = b1b;
+    if (single) Z[0] = {b1a, b1b};
+    else {
+      oa[0] = b1a;
+      ob[0] = b1b;
+    }
     rsa += b1a;
     rsb += b1b;
   }
@@ -290,14 +308,19 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     double reb = 0.5 * (z1.y + z2.y), imb = -0.5 * (z1.x - z2.x);
     runa += rea;
     runb += reb;
-    oa[2 * k - 1] = -ima; // b[2k]
-    oa[2 * k] = runa;     // b[2k+1]
+    if (single) {
+      Z[k] = {-ima, runa};
+      Z[N - k] = {-imb, runb};
+    } else {
+      oa[2 * k - 1] = -ima; // b[2k]
+      oa[2 * k] = runa;     // b[2k+1]
+      ob[2 * k - 1] = -imb;
+      ob[2 * k] = runb;
+    }
     rsa += runa - ima;
-    ob[2 * k - 1] = -imb;
-    ob[2 * k] = runb;
     if (has_b) rsb += runb - imb;
   }
-  // n even: the last even output b[n] = -Im Y_{n/2} has no odd partner
+  // n even: the last even output b[n] = -Im Y_{n/2} has no odd partner (never with one buffer: N is even there)
   if (!(n & 1) && tid == NT - 1) {
     int k = n / 2;
     cplx z1 = Z[k], z2 = Z[N - k];
@@ -308,25 +331,40 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     if (has_b) rsb += -imb;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += NT) {
-    rowa[i] = oa[i];
-    if (has_b) rowb[i] = ob[i];
+  if (single) {
+    for (int i = tid; i < n; i += NT) {
+      const int k = (i + 1) >> 1;
+      const cplx za = Z[k], zb = Z[(N - k) % N];
+      const bool first = (i == 0) || (i & 1);
+      rowa[i] = first ? za.x : za.y;
+      if (has_b) rowb[i] = (i == 0) ? za.y : ((i & 1) ? zb.x : zb.y);
+    }
+  } else {
+    for (int i = tid; i < n; i += NT) {
+      rowa[i] = oa[i];
+      if (has_b) rowb[i] = ob[i];
+    }
   }
   if (ROWSUM) {
-    __syncthreads();
-    red[tid] = rsa;
-    red[NT + tid] = rsb;
-    __syncthreads();
-    for (int off = NT / 2; off > 0; off >>= 1) {
-      if (tid < off) {
-        red[tid] += red[tid + off];
-        red[NT + tid] += red[NT + tid + off];
-      }
-      __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      rsa += __shfl_xor(rsa, off);
+      rsb += __shfl_xor(rsb, off);
     }
+    __syncthreads();
+    if (lane == 0) {
+      red[wv] = rsa;
+      red[NT / 64 + wv] = rsb;
+    }
+    __syncthreads();
     if (tid == 0) {
-      P.rowsum[(long)m * ny + (ja - 1)] = red[0];
-      if (has_b) P.rowsum[(long)m * ny + ja] = red[NT];
+      double ta = 0.0, tb = 0.0;
+      for (int w = 0; w < NT / 64; ++w) {
+        ta += red[w];
+        tb += red[NT / 64 + w];
+      }
+      P.rowsum[(long)m * ny + (ja - 1)] = ta;
+      if (has_b) P.rowsum[(long)m * ny + ja] = tb;
     }
   }
 }

@@ -354,15 +354,15 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipMalloc((void **)&c->sintab, sizeof(double) * st.size()));
   HIPCHECK(hipMemcpy(c->twid, tw.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(c->sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
-  // generic row kernels: two ping-pong buffers, or ONE buffer with in-place stages for long rows (cyclic kernel)
+  // generic row kernels: two ping-pong buffers, or ONE buffer with in-place stages for long rows
   c->dst_single = false;
-  if (g.cyc && N >= DST_SINGLE_MINN && N <= DST_SINGLE_MAXN && N % 2 == 0 && !getenv("QGCM_HIP_NO_SINGLE_BUFFER")) {
+  if (N >= DST_SINGLE_MINN && N <= DST_SINGLE_MAXN && N % 2 == 0 && !getenv("QGCM_HIP_NO_SINGLE_BUFFER")) {
     c->dst_single = true;
     for (int f = 0; f < c->nfac; ++f)
       if (c->fac[f] != 2 && c->fac[f] != 3 && c->fac[f] != 4 && c->fac[f] != 5 && c->fac[f] != 8) c->dst_single = false;
   }
   c->dst_lds = (size_t)(c->dst_single ? 1 : 2) * N * sizeof(cplx) + 2 * (g.cyc ? RFFT_NT : (N >= DST_BIG_N ? DST_NT_BIG : DST_NT)) * sizeof(double);
-  if (c->dst_single) c->dst_lds = (size_t)N * sizeof(cplx) + 2 * (RFFT_NT / 64) * sizeof(double);
+  if (c->dst_single) c->dst_lds = (size_t)N * sizeof(cplx) + 2 * (RFFT_NT / 64) * sizeof(double); // RFFT_NT == DST_NT_BIG
   if (c->dst_lds > 160 * 1024) QG_FAIL("qgcm_hip_set_grid: nxto=%d needs %zu B of LDS per row pair (> 160 KiB)", N, c->dst_lds);
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
