@@ -257,6 +257,32 @@ def test_dynamic_topography_and_entrainment_fields():
             mod.close()
 
 
+@pytest.mark.parametrize("nxto,cyclic", [(3072, False), (4096, False), (5000, False), (2880, True), (4608, True), (2400, False)])
+def test_long_row_transform_sizes(nxto, cyclic):
+    """Generic row kernels on long rows: 2561 <= nxto <= 5104 runs the single-buffer in-place stages (two
+    workgroups per CU), below that the two-buffer Stockham plan with 512 threads; radix mixes 8/4/2/3/5.
+    The Helmholtz solver (row transform, sweeps, row transform) against the CPU oracle on a 33-row basin."""
+    from qgcm_hip import OceanModel
+    from qgcm_hip.config import OceanConfig
+    base = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True) if cyclic else dict(fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
+    nxa = nxto // 8
+    cfg = OceanConfig("long_%d" % nxto, nxa if cyclic else nxa + 2, 6, nxa, 4, 8, 3, dxo=5.0e3, **base)
+    assert cfg.nxto == nxto and cfg.nyto == 32
+    o = make_oracle(cfg)
+    m = OceanModel(cfg)
+    try:
+        rng = np.random.default_rng(nxto)
+        rhs = np.asfortranarray(rng.standard_normal((cfg.nxpo, cfg.nypo)))
+        if cyclic:
+            rhs[-1, :] = rhs[0, :]
+        for mode in range(cfg.nlo):
+            boc = m.bd2oc - m.rdm2oc[mode]
+            assert relerr(m.helmholtz(rhs, boc), o.helmholtz(rhs, boc)) < TOL_CALL, mode
+    finally:
+        m.close()
+        o.close()
+
+
 def test_fused_inverse_transform_unpack_bitwise():
     """k_dst64_unpack (inverse row transform + modes -> layers + boundary PV in one launch) against
     the separate k_dst64 / k_unpack_box (/ k_ocqbdy) launches: same expressions, so bitwise equal --
