@@ -133,4 +133,33 @@ contains
     if (solnok) ok = 1
   end subroutine ref_valids
 
+  ! Restart dump in the wire format of SUBROUTINE resave (src/q-gcm.F:3053-3088; that routine lives in the main
+  ! program file and cannot be linked here, so its WRITE sequence for an ocean_only build is restated): unformatted
+  ! sequential records  tyrs | po,pom | sst,sstm | ast,astm | hmixa,hmixam.
+  subroutine ref_write_restart(fname, nchar, tyrs_in) bind(C, name='ref_write_restart')
+    integer(c_int), value :: nchar
+    character(kind=c_char), intent(in) :: fname(nchar)
+    real(c_double), value :: tyrs_in
+    character(len=nchar) :: f
+    integer :: i
+    double precision :: tyrs
+    do i = 1, nchar
+      f(i:i) = fname(i)
+    enddo
+    tyrs = tyrs_in
+    open (77, file=f, form='unformatted', status='replace')
+    write (77) tyrs
+    write (77) po,pom
+    write (77) sst,sstm
+    write (77) ast,astm
+    write (77) hmixa,hmixam
+    close (77)
+  end subroutine ref_write_restart
+
+  subroutine ref_atmos_dims(nxa, nya) bind(C, name='ref_atmos_dims')
+    integer(c_int), intent(out) :: nxa, nya
+    nxa = nxta
+    nya = nyta
+  end subroutine ref_atmos_dims
+
 end module qgcm_ref_oml

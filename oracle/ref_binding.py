@@ -182,6 +182,17 @@ class RefLib:
         self.lib.ref_steps_oml.argtypes = [C.c_int, C.c_int]
         run_big_stack(self.lib.ref_steps_oml, int(s0), int(n))
 
+    def write_restart(self, path, tyrs):
+        """Unformatted restart dump in the reference's record sequence (src/q-gcm.F:3076-3086)."""
+        b = path.encode()
+        self.lib.ref_write_restart.argtypes = [C.c_char_p, C.c_int, C.c_double]
+        self.lib.ref_write_restart(b, len(b), float(tyrs))
+
+    def atmos_dims(self):
+        a, b = C.c_int(), C.c_int()
+        self.lib.ref_atmos_dims(C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def valids(self, dtopoc=None):
         """The reference's verdict solnok (src/valsubs.F:43); its prints go to stdout."""
         d = self._f2() if dtopoc is None else np.asfortranarray(dtopoc, dtype=np.float64)
