@@ -140,11 +140,18 @@ int qgcm_hip_helmholtz(qgcm_hip_handle h, double *wrk, const double *boc);
  * asynchronous on the handle's stream. */
 int qgcm_hip_local_rows(qgcm_hip_handle h, int *nyl, int *joff, int *jlo, int *jhi);
 int qgcm_hip_row_transform(qgcm_hip_handle h, int inverse);
-/* number of doubles of one slab summary message: 7 * nlo * ldw */
+/* number of doubles of one per-step slab summary message: 3 * nlo * ldw */
 int qgcm_hip_thomas_msg_len(qgcm_hip_handle h);
+/* The right-hand-side independent part of the summaries (gains and unit-response sums, 4 * nlo * ldw doubles per
+ * slab) is exchanged ONCE after qgcm_hip_set_grid: every rank copies its own with qgcm_hip_thomas_consts, the host
+ * all-gathers them (rank-major) and hands the result to qgcm_hip_set_thomas_consts. qgcm_hip_comm_init does this
+ * by itself for the library-issued exchanges; a lone slab (nranks = 1) needs nothing. */
+int qgcm_hip_thomas_const_len(qgcm_hip_handle h);
+int qgcm_hip_thomas_consts(qgcm_hip_handle h, double *dst_dev);
+int qgcm_hip_set_thomas_consts(qgcm_hip_handle h, const double *gath_dev, int nranks);
 /* phase 1: this slab's summary of the two y sweeps -> send_dev: per mode and wavenumber the zero-inflow
- *          end values of both sweeps, the gains, and the column sums that make up the area integrals
- *          (xintp, src/ocisubs.F:160) - 7 numbers.
+ *          end values of both sweeps and the zero-inflow column sum behind the area integrals
+ *          (xintp, src/ocisubs.F:160) - 3 numbers.
  * phase 2: gath_dev = all ranks' phase-1 messages (rank-major) -> both sweeps finished, and the
  *          basin-wide area integrals known on every rank (bitwise the same). */
 int qgcm_hip_thomas_phase(qgcm_hip_handle h, int phase, const double *gath_dev, double *send_dev,
@@ -173,7 +180,7 @@ int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_d
  *   qgcm_hip_comm_init      : collective over the nranks handles (one process per GPU); rank r must own the
  *                             r-th slab (slab_g0/slab_g1 of qgcm_hip_params); allocates the exchange buffers
  *   qgcm_hip_slab_steps     : n whole steps from step s0 (collective). Per step: all-gather of the slab
- *                             summaries (7*nlo*ldw doubles) and the edge rows (3 of po + 1 of qo per layer) to
+ *                             summaries (3*nlo*ldw doubles) and the edge rows (3 of po + 1 of qo per layer) to
  *                             both neighbours as one all-gather, or as send/recv with QGCM_HIP_HALO_P2P=1.
  *                             QGCM_HIP_SLAB_GRAPH=1 replays 50-step HIP graphs that contain the collectives.
  * The communicator is released by qgcm_hip_destroy. */

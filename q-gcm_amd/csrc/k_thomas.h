@@ -63,14 +63,16 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // linear in the inflows too:  sum_j v_j = S0 + uin*SP + vin*SQ  (S0: zero-inflow sum, SP / SQ:
 // sums of the unit responses, right-hand-side independent), so every rank forms the basin-wide
 // ksum from the one all-gather of the slab summaries - bitwise the same on every rank.
-// PHASE 1  publish (Cf, D, Cb, E, S0, SP, SQ) per wavenumber; nothing is written to wrk.
+// PHASE 1  publish (Cf, Cb, S0) per wavenumber; nothing is written to wrk.
 // PHASE 2  compose all ranks' summaries into uin, vin and the basin-wide ksum (lanes = ranks,
 //          two affine scans), finish both sweeps, write.
 // PHASE 4  set-up: D, E and SP of this slab (input column = 0, unit inflow from below).
 // PHASE 5  set-up: SQ (input column = 0, unit inflow from above).
-// message layout of one rank: TH_MSG doubles at TH_MSG*(m*ldw + k)
+// per-step message of one rank: TH_MSG doubles (Cf, Cb, S0) at TH_MSG*(m*ldw + k); the right-hand-side independent
+// part (D, E, SP, SQ: TH_CST doubles, the layout of slabDE) is exchanged ONCE after set-up (cgath)
 // grid: (ceil(nk/16), nlayers)
-#define TH_MSG 7
+#define TH_MSG 3
+#define TH_CST 4
 template <int R, int PHASE>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __shared__ double sC[TH_NC][TH_KW];
@@ -130,9 +132,10 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   if (PHASE == 2) {
     // lane s stands for rank s (at most 64 slabs); wave wv works on wavenumber kq
     const bool act = lane < P.nranks && kq < P.g.nk;
-    const double *gs = P.gath + (long)lane * msg + mk;
-    const double gCf = act ? gs[0] : 0.0, gD = act ? gs[1] : 1.0, gCb = act ? gs[2] : 0.0, gE = act ? gs[3] : 0.0;
-    const double gS0 = act ? gs[4] : 0.0, gSP = act ? gs[5] : 0.0, gSQ = act ? gs[6] : 0.0;
+    const double *gs = P.gath + (long)lane * msg + mk;                                        // this step's summaries
+    const double *gc = P.cgath + (long)lane * (TH_CST * P.g.nl * ldw) + TH_CST * ((long)m * ldw + kq); // set-up constants
+    const double gCf = act ? gs[0] : 0.0, gCb = act ? gs[1] : 0.0, gS0 = act ? gs[2] : 0.0;
+    const double gD = act ? gc[0] : 1.0, gE = act ? gc[1] : 0.0, gSP = act ? gc[2] : 0.0, gSQ = act ? gc[3] : 0.0;
     // forward chain: value leaving rank s = Cf_s + D_s * (value entering rank s), nothing enters rank 0
     double Cs = gCf, Ds = gD;
     affine_scan(Cs, Ds, lane);
@@ -239,12 +242,8 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     P.ksum[(long)m * ldw + kq] = ft * tot;
   } else if (PHASE == 1) {
     P.send[mk] = Cf_tot;
-    P.send[mk + 1] = cst[0];
-    P.send[mk + 2] = Cb_tot;
-    P.send[mk + 3] = cst[1];
-    P.send[mk + 4] = tot;
-    P.send[mk + 5] = cst[2];
-    P.send[mk + 6] = cst[3];
+    P.send[mk + 1] = Cb_tot;
+    P.send[mk + 2] = tot;
   } else if (PHASE == 4) {
     cst[0] = D_tot;
     cst[1] = Cb_tot;

@@ -81,7 +81,8 @@ struct QgDstParams {
 
 struct QgThomasParams {
   QgGeom g;
-  const double *gath; // distributed sweep: all ranks' slab maps (rank-major), else nullptr
+  const double *gath; // distributed sweep: all ranks' per-step summaries (rank-major), else nullptr
+  const double *cgath; // distributed sweep: all ranks' set-up constants (slabDE of every rank, rank-major)
   double *send;       // distributed sweep: this rank's slab map
   double *slabDE;     // (4, ldw, nl): D, E, SP, SQ of this slab (PHASE 4/5 write, PHASE 1 reads)
   double *ksum;       // (ldw, nl): ftnorm * column sums of the solution per spectral index (see k_thomas.h)

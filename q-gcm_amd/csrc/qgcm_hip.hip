@@ -54,6 +54,8 @@ struct qgcm_hip_ctx {
   double *wrk, *rowsum;
   double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
   double *slabDE;                          // y-slab summary constants (D, E, SP, SQ) per (mode, wavenumber)
+  double *th_cgath = nullptr;              // all ranks' slabDE (rank-major), exchanged once (qgcm_hip_set_thomas_consts)
+  int th_cgath_ranks = 0;
   double *ksum, *wcot;                     // spectral column sums of the solution and their cot weights (k_thomas.h)
   int *rconv, *rconv_tmp;                  // row from which the Thomas pivots are stationary
   double *bpart;                           // cyclic: partial boundary line sums (k_cyc_bsums -> k_constr_cyc)
@@ -245,7 +247,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
       if (p) hipFree(p);
     delete m;
   }
-  double *vp[] = {c->val_part, c->val_out, c->dtopoc};
+  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath};
   for (double *p : vp)
     if (p) hipFree(p);
   double *omp[] = {c->oml.sst[0], c->oml.sst[1], c->oml.sst[2], c->oml.fnet, c->oml.wekto, c->oml.xfo,
@@ -715,6 +717,9 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
   P.g = g;
   P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
   P.slabDE = c->slabDE;
+  P.cgath = (nranks == 1) ? c->slabDE : c->th_cgath; // a lone slab is its own rank 0
+  if (phase == 2 && nranks > 1 && (!c->th_cgath || c->th_cgath_ranks != nranks))
+    QG_FAIL("qgcm_hip_thomas_phase: the set-up constants of the %d slabs have not been exchanged (qgcm_hip_set_thomas_consts)", nranks);
   P.ksum = c->ksum;
   P.wrk = wrk;
   P.boc = boc;
@@ -1344,6 +1349,30 @@ extern "C" int qgcm_hip_row_transform(qgcm_hip_handle c, int inverse) {
 
 extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? TH_MSG * c->g.nl * c->g.ldw : 0; }
 
+extern "C" int qgcm_hip_thomas_const_len(qgcm_hip_handle c) { return c ? TH_CST * c->g.nl * c->g.ldw : 0; }
+
+extern "C" int qgcm_hip_thomas_consts(qgcm_hip_handle c, double *dst_dev) {
+  if (check_ready(c, "qgcm_hip_thomas_consts")) return 1;
+  if (!dst_dev) QG_FAIL("qgcm_hip_thomas_consts: null buffer");
+  HIPCHECK(hipMemcpyAsync(dst_dev, c->slabDE, sizeof(double) * TH_CST * c->g.nl * c->g.ldw, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int qgcm_hip_set_thomas_consts(qgcm_hip_handle c, const double *gath_dev, int nranks) {
+  if (check_ready(c, "qgcm_hip_set_thomas_consts")) return 1;
+  if (!gath_dev || nranks < 1 || nranks > 64) QG_FAIL("qgcm_hip_set_thomas_consts: bad argument");
+  const size_t n = (size_t)TH_CST * c->g.nl * c->g.ldw * nranks;
+  if (c->th_cgath_ranks != nranks) {
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (c->th_cgath) hipFree(c->th_cgath);
+    c->th_cgath = nullptr;
+    if (dalloc(&c->th_cgath, n)) return 1;
+    c->th_cgath_ranks = nranks;
+  }
+  HIPCHECK(hipMemcpyAsync(c->th_cgath, gath_dev, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
 extern "C" int qgcm_hip_thomas_phase(qgcm_hip_handle c, int phase, const double *gath_dev, double *send_dev, int rank,
                                      int nranks) {
   if (check_ready(c, "qgcm_hip_thomas_phase")) return 1;
@@ -1466,6 +1495,15 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   for (auto &b : bufs) {
     HIPCHECK(hipMalloc((void **)b.p, b.n * sizeof(double)));
     HIPCHECK(hipMemsetAsync(*b.p, 0, b.n * sizeof(double), c->stream));
+  }
+  // the right-hand-side independent part of the slab summaries (D, E, SP, SQ) is exchanged once
+  if (nranks > 1) {
+    const size_t nc = (size_t)TH_CST * g.nl * g.ldw;
+    if (c->th_cgath) hipFree(c->th_cgath);
+    c->th_cgath = nullptr;
+    if (dalloc(&c->th_cgath, nc * nranks)) return 1;
+    c->th_cgath_ranks = nranks;
+    NCCLCHECK(api, api->AllGather(c->slabDE, c->th_cgath, nc, ncclDouble, m->comm, c->stream));
   }
   HIPCHECK(hipStreamSynchronize(c->stream));
   const char *gm = getenv("QGCM_HIP_SLAB_GRAPH");

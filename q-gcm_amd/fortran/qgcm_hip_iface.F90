@@ -183,6 +183,20 @@ module qgcm_hip_iface
       type(c_ptr), value :: h
       integer(c_int), value :: s0, n
     end function
+    ! own exchanges: the right-hand-side independent part of the slab summaries, once after set_grid
+    integer(c_int) function qgcm_hip_thomas_const_len(h) bind(C, name='qgcm_hip_thomas_const_len')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_thomas_consts(h, dst_dev) bind(C, name='qgcm_hip_thomas_consts')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, dst_dev
+    end function
+    integer(c_int) function qgcm_hip_set_thomas_consts(h, gath_dev, nranks) bind(C, name='qgcm_hip_set_thomas_consts')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, gath_dev
+      integer(c_int), value :: nranks
+    end function
     integer(c_int) function qgcm_hip_comm_set_halo_p2p(h, on) bind(C, name='qgcm_hip_comm_set_halo_p2p')
       import :: c_ptr, c_int
       type(c_ptr), value :: h

@@ -48,6 +48,7 @@ SYMBOLS = [
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
+    "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
     "qgcm_hip_constr", "qgcm_hip_unpack",
     "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack", "qgcm_hip_slab_stage",
     "qgcm_hip_comm_unique_id", "qgcm_hip_comm_init", "qgcm_hip_slab_steps", "qgcm_hip_comm_set_halo_p2p",
@@ -92,6 +93,9 @@ def load_library():
     L.qgcm_hip_local_rows.argtypes = [vp, ip, ip, ip, ip]
     L.qgcm_hip_row_transform.argtypes = [vp, C.c_int]
     L.qgcm_hip_thomas_msg_len.argtypes = [vp]
+    L.qgcm_hip_thomas_const_len.argtypes = [vp]
+    L.qgcm_hip_thomas_consts.argtypes = [vp, vp]
+    L.qgcm_hip_set_thomas_consts.argtypes = [vp, vp, C.c_int]
     L.qgcm_hip_thomas_phase.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int]
     L.qgcm_hip_constr.argtypes = [vp]
     L.qgcm_hip_unpack.argtypes = [vp, C.c_int]

@@ -198,6 +198,7 @@ class HipSlab:
         self.sync_each_call = sync_each_call
         self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
         self.th_len = self.L.qgcm_hip_thomas_msg_len(self.h)
+        self.cst_len = self.L.qgcm_hip_thomas_const_len(self.h)
         self.halo_len = self.L.qgcm_hip_halo_msg_len(self.h)
         self.stream_ptr = self.L.qgcm_hip_stream(self.h)
 
@@ -256,6 +257,14 @@ class HipSlab:
         check(self.L.qgcm_hip_thomas_phase(self.h, int(phase), self._ptr(gath), self._ptr(send), self.rank, self.nranks))
         self._done()
 
+    def thomas_consts(self, dst):
+        """This slab's right-hand-side independent summary constants -> dst (device buffer of cst_len doubles)."""
+        check(self.L.qgcm_hip_thomas_consts(self.h, self._ptr(dst))); self._done()
+
+    def set_thomas_consts(self, gath):
+        """All ranks' constants (rank-major); once after set-up."""
+        check(self.L.qgcm_hip_set_thomas_consts(self.h, self._ptr(gath), self.nranks)); self._done()
+
     def constr(self):
         check(self.L.qgcm_hip_constr(self.h)); self._done()
 
@@ -309,6 +318,17 @@ class SlabOcean:
         self.h_from_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
         self.h_from_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
         self.step_index = 1
+        # the right-hand-side independent part of the slab summaries is exchanged once
+        if self.P > 1:
+            cs_send = [s.new_buffer(s.cst_len) for s in slabs]
+            cs_gath = [s.new_buffer(s.cst_len * self.P) for s in slabs]
+            for i, x in enumerate(slabs):
+                x.thomas_consts(cs_send[i])
+            self._comm(comm.all_gather, cs_gath, cs_send)
+            for i, x in enumerate(slabs):
+                x.set_thomas_consts(cs_gath[i])
+            for x in slabs:
+                x.sync()
 
     def _comm(self, fn, *a):
         if self.stream_ctx is None:

@@ -32,7 +32,9 @@ class NumpySlab:
         # owned rows that are interior to the global domain (0-based local indices)
         self.r0 = self.jlo - 1 + (1 if g0 == 1 else 0)
         self.r1 = self.jhi - 1 - (1 if g1 == self.nyg else 0)
-        self.th_len = 7 * nl * self.nk
+        self.th_len = 3 * nl * self.nk
+        self.cst_len = 4 * nl * self.nk
+        self.cgath = None
         # weights of the spectral area integral: sum_i 2 sin(k i pi/n) = 2 cot(k pi/2n) for odd k (k_thomas.h)
         n = nx - 1
         kk = np.arange(1, self.nk + 1)
@@ -186,30 +188,51 @@ class NumpySlab:
         if phase == 1:
             u0 = self._fwd(w, z)
             v0 = self._bwd(u0, z)
-            bp = self._bwd(self._fwd(np.zeros_like(w), one), z)   # backward image of the unit forward response
-            q = self._bwd(np.zeros_like(w), one)                   # unit backward response
-            D = np.prod(-a * self.bet, axis=1)
-            t = send.numpy().reshape(nl, nk, 7)
-            for i, x in enumerate((u0[:, -1, :], D, v0[:, 0, :], bp[:, 0, :], v0.sum(axis=1), bp.sum(axis=1), q.sum(axis=1))):
+            t = send.numpy().reshape(nl, nk, 3)
+            for i, x in enumerate((u0[:, -1, :], v0[:, 0, :], v0.sum(axis=1))):
                 t[:, :, i] = x.T
             return
-        g = gath.numpy().reshape(self.nranks, nl, nk, 7).transpose(0, 2, 1, 3)  # (P, nk, nl, 7)
+        g = gath.numpy().reshape(self.nranks, nl, nk, 3).transpose(0, 2, 1, 3)  # (P, nk, nl, 3): Cf, Cb, S0
+        if self.nranks == 1:
+            k = self._consts().reshape(1, nl, nk, 4).transpose(0, 2, 1, 3)
+        else:
+            k = self.cgath.reshape(self.nranks, nl, nk, 4).transpose(0, 2, 1, 3)   # (P, nk, nl, 4): D, E, SP, SQ
         us = []
         u = z
         for r in range(self.nranks):
             us.append(u)
-            u = g[r, :, :, 0] + g[r, :, :, 1] * u
+            u = g[r, :, :, 0] + k[r, :, :, 0] * u
         vs = [None] * self.nranks
         v = z
         for r in range(self.nranks - 1, -1, -1):
             vs[r] = v
-            v = g[r, :, :, 2] + g[r, :, :, 3] * us[r] + g[r, :, :, 1] * v
+            v = g[r, :, :, 1] + k[r, :, :, 1] * us[r] + k[r, :, :, 0] * v
         tot = z
         for r in range(self.nranks):
-            tot = tot + (g[r, :, :, 4] + us[r] * g[r, :, :, 5] + vs[r] * g[r, :, :, 6])
+            tot = tot + (g[r, :, :, 2] + us[r] * k[r, :, :, 2] + vs[r] * k[r, :, :, 3])
         self.ksum = ft * tot
         uf = self._fwd(w, us[self.rank])
         self.wrk[:, self.r0:self.r1 + 1, :] = ft * self._bwd(uf, vs[self.rank])
+
+    def _consts(self):
+        """(nl, nk, 4) = D, E, SP, SQ of this slab: right-hand-side independent."""
+        a = self.c["aoc"]
+        nl, nk = self.cfg.nlo, self.nk
+        z, one = np.zeros((nk, nl)), np.ones((nk, nl))
+        w0 = np.zeros((nk, self.r1 - self.r0 + 1, nl))
+        bp = self._bwd(self._fwd(w0, one), z)   # backward image of the unit forward response
+        q = self._bwd(w0, one)                  # unit backward response
+        D = np.prod(-a * self.bet, axis=1)
+        out = np.zeros((nl, nk, 4))
+        for i, x in enumerate((D, bp[:, 0, :], bp.sum(axis=1), q.sum(axis=1))):
+            out[:, :, i] = x.T
+        return out
+
+    def thomas_consts(self, dst):
+        dst.numpy()[:] = self._consts().reshape(-1)
+
+    def set_thomas_consts(self, gath):
+        self.cgath = gath.numpy().copy()
 
     def constr(self):
         cfg, c = self.cfg, self.c
