@@ -11,6 +11,9 @@
  * /root/reference/src (oracle/build_ref.sh -> oracle/_ref/) and against the
  * golden vectors under tests/golden/ that were generated from that build
  * (tests/golden/make_golden.py).  See tests/test_oracle_vs_golden.py.
+ * The mixed layer (qgo_oml) is pinned bitwise by three reference builds (tests/golden/make_golden_oml.py,
+ * tests/test_oml_oracle.py), the validity scan (qgo_valids) by the reference's verdicts on 16 crafted states
+ * (tests/golden/make_golden_valids.py, tests/test_valids_oracle.py).
  *
  * Arrays are Fortran ordered: element (i,j,k), 1-based, lives at
  * (i-1) + nxpo*((j-1) + nypo*(k-1)).
