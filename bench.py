@@ -286,6 +286,11 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                 slab.set_halo_p2p(False)
             wall_l, fin_l = measure()
             driver += "; torch.distributed driver: %.1f us/step" % (1e6 * wall_t / args.steps)
+            try:  # what the exchanges cost by themselves on this node (for the record)
+                pr = slab.comm_probe(200)
+                driver += "; exchanges alone: summaries all-gather %.1f us, halo all-gather %.1f us, halo send/recv %.1f us" % tuple(pr)
+            except Exception as e:  # noqa: BLE001
+                print("exchange probe failed: %r" % (e,), file=sys.stderr)
             if fin_l and wall_l <= wall_t:
                 best = (wall_l, fin_l, driver)
             else:

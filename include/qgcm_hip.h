@@ -191,6 +191,9 @@ int qgcm_hip_slab_steps(qgcm_hip_handle h, int s0, int n);
 /* edge rows as grouped send/recv with the two neighbours (1) or as one all-gather (0); collective:
  * every rank must make the same choice */
 int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle h, int on);
+/* measurement aid (collective): the step's exchanges back to back, microseconds each:
+ * us[0] summaries all-gather, us[1] halo rows as all-gather, us[2] halo rows as send/recv */
+int qgcm_hip_comm_probe(qgcm_hip_handle h, int reps, double *us);
 
 /* ---- ocean mixed layer -----------------------------------
  * `call oml` (src/q-gcm.F:1232; body src/omlsubs.F:47-236 + omladf 244-763) on the device: steps the

@@ -1522,6 +1522,53 @@ extern "C" int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle c, int on) {
   return 0;
 }
 
+// Measurement aid: the step's collectives issued back to back on the handle's stream, HIP-event timed
+// (collective over all ranks). us[0] = all-gather of the slab summaries, us[1] = halo rows as one all-gather,
+// us[2] = halo rows as grouped send/recv with the two neighbours.
+extern "C" int qgcm_hip_comm_probe(qgcm_hip_handle c, int reps, double *us) {
+  if (!c || !c->sc_comm) QG_FAIL("qgcm_hip_comm_probe: no communicator (qgcm_hip_comm_init)");
+  if (!us || reps < 1) QG_FAIL("qgcm_hip_comm_probe: bad argument");
+  QgSlabComm *m = c->sc_comm;
+  const int r = m->rank, P = m->nranks;
+  const size_t n = m->halo_len;
+  hipEvent_t a, b;
+  HIPCHECK(hipEventCreate(&a));
+  HIPCHECK(hipEventCreate(&b));
+  for (int which = 0; which < 3; ++which) {
+    for (int pass = 0; pass < 2; ++pass) { // pass 0 warms the algorithm / channel set-up
+      const int nrep = pass ? reps : 3;
+      HIPCHECK(hipEventRecord(a, c->stream));
+      for (int i = 0; i < nrep; ++i) {
+        if (which == 0) {
+          NCCLCHECK(m->api, m->api->AllGather(m->th_send, m->th_gath, m->th_len, ncclDouble, m->comm, c->stream));
+        } else if (which == 1) {
+          NCCLCHECK(m->api, m->api->AllGather(m->h_send, m->h_gath, 2 * n, ncclDouble, m->comm, c->stream));
+        } else if (P > 1) {
+          double *rl = m->h_gath + (size_t)(2 * (r > 0 ? r - 1 : 0) + 1) * n, *rh = m->h_gath + (size_t)(2 * (r < P - 1 ? r + 1 : 0)) * n;
+          NCCLCHECK(m->api, m->api->GroupStart());
+          if (r > 0) {
+            NCCLCHECK(m->api, m->api->Send(m->h_send, n, ncclDouble, r - 1, m->comm, c->stream));
+            NCCLCHECK(m->api, m->api->Recv(rl, n, ncclDouble, r - 1, m->comm, c->stream));
+          }
+          if (r < P - 1) {
+            NCCLCHECK(m->api, m->api->Send(m->h_send + n, n, ncclDouble, r + 1, m->comm, c->stream));
+            NCCLCHECK(m->api, m->api->Recv(rh, n, ncclDouble, r + 1, m->comm, c->stream));
+          }
+          NCCLCHECK(m->api, m->api->GroupEnd());
+        }
+      }
+      HIPCHECK(hipEventRecord(b, c->stream));
+      HIPCHECK(hipEventSynchronize(b));
+      float ms = 0.f;
+      HIPCHECK(hipEventElapsedTime(&ms, a, b));
+      if (pass) us[which] = 1e3 * ms / nrep;
+    }
+  }
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return 0;
+}
+
 // one distributed ocean step: three communication-free stages (the same calls SlabOcean.step makes through
 // qgcm_hip_slab_stage) and two exchanges, all ordered on c->stream; no host synchronisation
 static int slab_step(qgcm_hip_ctx *c, int s) {

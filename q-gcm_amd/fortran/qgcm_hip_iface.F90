@@ -197,6 +197,12 @@ module qgcm_hip_iface
       type(c_ptr), value :: h, gath_dev
       integer(c_int), value :: nranks
     end function
+    integer(c_int) function qgcm_hip_comm_probe(h, reps, us) bind(C, name='qgcm_hip_comm_probe')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: reps
+      real(c_double), intent(out) :: us(3)
+    end function
     integer(c_int) function qgcm_hip_comm_set_halo_p2p(h, on) bind(C, name='qgcm_hip_comm_set_halo_p2p')
       import :: c_ptr, c_int
       type(c_ptr), value :: h

@@ -286,6 +286,12 @@ class HipSlab:
         check(self.L.qgcm_hip_comm_init(self.h, comm_id, len(comm_id), self.rank, self.nranks))
         self.has_comm = True
 
+    def comm_probe(self, reps=200):
+        """The step's exchanges back to back (collective): us per summaries all-gather, halo all-gather, halo send/recv."""
+        us = (C.c_double * 3)()
+        check(self.L.qgcm_hip_comm_probe(self.h, int(reps), us))
+        return [us[0], us[1], us[2]]
+
     def set_halo_p2p(self, on):
         check(self.L.qgcm_hip_comm_set_halo_p2p(self.h, int(on)))
 
