@@ -445,6 +445,25 @@ def main():
                                        "oml_kernels_us_bracketed": round(1e3 * pr2["k_oml"][0] / max(pr2["k_oml"][1], 1) - bracket_us, 3)}
         except Exception as e:  # noqa: BLE001 - secondary figure only
             out["with_mixed_layer"] = {"error": repr(e)}
+        # Secondary figure: BASELINE configs[2], the zonally cyclic Southern Ocean channel at 5 km (4609 x 577 x 3)
+        try:
+            from qgcm_hip import synth as _synth
+            cfg_s = preset("socn5")
+            ms_ = OceanModel(cfg_s, device=local_rank)
+            po_s = _synth.gaussian_eddy(cfg_s)
+            tx_s, ty_s = _synth.wind_stress(cfg_s)
+            _, wek_s = _synth.wekpo_from_tau(cfg_s, tx_s, ty_s)
+            ms_.set_p(po_s, po_s)
+            ms_.set_forcing(wek_s, np.zeros_like(wek_s), np.zeros(cfg_s.nlo - 1))
+            ms_.set_cyc_forcing(*_synth.tau_line_integrals(cfg_s, tx_s))
+            ms_.steps(100, s0=1)
+            t_s = ms_.time_steps(400, s0=101)
+            ok_s = bool(np.isfinite(ms_.get_state()[0]).all())
+            ms_.close()
+            out["socn5_cyclic"] = {"steps_per_s": round(400 / (t_s * 1e-3), 2), "ms_per_step": round(t_s / 400, 5),
+                                   "grid": [cfg_s.nxpo, cfg_s.nypo, cfg_s.nlo], "state_finite": ok_s}
+        except Exception as e:  # noqa: BLE001 - secondary figure only
+            out["socn5_cyclic"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             model.close()
             out["cpu_baseline"] = cpu_baseline(cfg, po, wek)
