@@ -16,6 +16,10 @@
 // Workgroups are renumbered so that each XCD (blockIdx mod 8) sweeps a
 // contiguous band of tile rows: the halo rows re-read by vertically adjacent
 // tiles then hit that XCD's own L2 instead of being re-fetched.
+// Tile shape: 16 x 16 points, 256 threads, one point per thread (72 VGPRs, 12 KB LDS: 7 workgroups per CU). The
+// kernel is bound by its chain of barrier-separated phases, so resident workgroups matter more than halo
+// re-reads: measured at 5 km 64x8 (2 points per thread, 5 per CU) 38.4 us, 32x8 35.0, 16x16 33.3, 16x8 35.1,
+// 32x16/512 threads 35.3, 16x32/512 36.2.
 // Expression association order is the reference's, and the library is built
 // with -ffp-contract=off, so qgostep reproduces the CPU reference bit for bit.
 //
@@ -26,11 +30,15 @@
 #pragma once
 #include "qgcm_dev.h"
 
-#define TEND_TX 64
-#ifndef TEND_TY
-#define TEND_TY 8
+#ifndef TEND_TX
+#define TEND_TX 16
 #endif
+#ifndef TEND_TY
+#define TEND_TY 16
+#endif
+#ifndef TEND_NT
 #define TEND_NT 256
+#endif
 
 template <bool CYC>
 __device__ __forceinline__ int tend_wrap(int gi, int nxt) {
