@@ -424,9 +424,12 @@ def main():
                                               "empty_launch_in_train": round(train_us, 3)},
                          "kernel_us": {k: round(1e3 * v[0] / max(v[1], 1), 3) for k, v in prof.items()}},
         }
+        secondary = os.environ.get("QGCM_BENCH_NO_SECONDARY") != "1"  # profiles/collect.sh profiles the main workload only
         # Secondary figure (not `value`): the same workload with the ocean mixed layer on the device
         # (`call oml`) - the end-to-end ocean-only step without any per-step PCIe traffic.
         try:
+            if not secondary:
+                raise RuntimeError("skipped (QGCM_BENCH_NO_SECONDARY=1)")
             from qgcm_hip import oml_preset, synth
             om = oml_preset(cfg)
             sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om)
@@ -447,6 +450,8 @@ def main():
             out["with_mixed_layer"] = {"error": repr(e)}
         # Secondary figure: BASELINE configs[2], the zonally cyclic Southern Ocean channel at 5 km (4609 x 577 x 3)
         try:
+            if not secondary:
+                raise RuntimeError("skipped (QGCM_BENCH_NO_SECONDARY=1)")
             from qgcm_hip import synth as _synth
             cfg_s = preset("socn5")
             ms_ = OceanModel(cfg_s, device=local_rank)

@@ -12,6 +12,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$R"
+export QGCM_BENCH_NO_SECONDARY=1   # profile the headline workload only (no mixed-layer / SOcn secondary figures)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 bench.py --no-cpu-baseline --steps 200 --warmup 20 > "$OUT/pmc_$C.log" 2>&1
