@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define QGCM_HIP_MAXL 8 /* max number of QG layers supported (nlo <= 8) */
-#define QGCM_HIP_ABI_VERSION 1
+#define QGCM_HIP_ABI_VERSION 2 /* 2: qgcm_hip_params.atmos + the atmosphere entry points */
 
 typedef struct qgcm_hip_ctx *qgcm_hip_handle;
 
@@ -69,6 +69,16 @@ typedef struct qgcm_hip_params {
    * set_/get_* is the LOCAL block (nxpo, nyl, .) with nyl = owned rows + a 3-row
    * halo on each side that has a neighbour (qgcm_hip_local_rows). */
   int slab_g0, slab_g1;
+  /* 1 = the handle is the ATMOSPHERIC channel of a coupled run: qgastep / atinvq / atqzbd
+   * (src/qgasubs.F:45-317, src/atisubs.F:60-395, src/vorsubs.F:396-480).  Zonally periodic (cyclic must be 1);
+   * the fields of this struct then carry MODULE atconst / parameters values under the ocean's names:
+   * nxpo,nypo,nlo = nxpa,nypa,nla; dxo,dyo = dxa,dya; tdto = tdta; bccooc = bccoat; ah4oc = ah4at; hoc = hat;
+   * gpoc = gpat; amatoc.. = amatat, ctl2mat, ctm2lat, rdm2at; aoc = aat; delek and ah2oc are ignored.
+   * Differences from the cyclic ocean that the kernels honour: layer 1 is the bottom layer (topography term
+   * in layer 1), forcing signs of src/qgasubs.F:128-131, no drag and no Del-4th term, constraint right-hand
+   * sides of src/atisubs.F:177-196, dpiat = integral of pa(k)-pa(k+1), src/vorsubs.F:470 as written,
+   * time levels averaged when mod(nt-1,100) == 0 (src/q-gcm.F:1370). */
+  int atmos;
 } qgcm_hip_params;
 
 /* ---- life cycle -------------------------------------------------------- */
@@ -127,6 +137,31 @@ int qgcm_hip_lf_average(qgcm_hip_handle h); /* ocean part of q-gcm.F:1328-1366 (
  * q-gcm.F:1222,1328).  Uses captured HIP graphs. */
 int qgcm_hip_steps(qgcm_hip_handle h, int s0, int n);
 int qgcm_hip_sync(qgcm_hip_handle h);
+
+/* ---- the atmosphere path (handles created with atmos = 1) ------------------
+ * One-for-one replacements of the three calls the main program makes every atmospheric step
+ * (src/q-gcm.F:1262-1268).  State and inputs move through the calls above under the ocean's names:
+ *   set_/get_state     pa, pam, qa, qam (nxpa,nypa,nla)                        MODULE atstate
+ *   set_forcing        wekpa, entat (nxpa,nypa), xan(nla-1)                    atstate / athomog (written by xforc / aml)
+ *   set_cyc_forcing    txisat, txinat, enisat(nla-1), eninat(nla-1)            athomog
+ *   set_/get_scalars   dpiat, dpiatp (nla-1), atmcs, atmcn, atmcsp, atmcnp (nla)
+ *   set_homog_cyc      pch1at, pch2at, pbhat, aipcha, hc1sat, hc2sat, hc1nat, hc2nat, hbsiat, aipbha
+ *   set_grid           yparel(nypa), bd2at(nxta) [FFTPACK order, src/q-gcm.F:961-970], ddynat(nxpa,nypa)
+ *   helmholtz          hscyat (src/atisubs.F:298-395) for homsol (src/conhoms.F:678-679)
+ *   lf_average         atmospheric half of the averaging block, src/q-gcm.F:1370-1404
+ *   steps(nt0, n)      n atmospheric steps nt = nt0.., averaging after the steps with mod(nt-1,100) == 0 */
+int qgcm_hip_qgastep(qgcm_hip_handle h);    /* replaces "call qgastep"          q-gcm.F:1262 */
+int qgcm_hip_atinvq(qgcm_hip_handle h);     /* replaces "call atinvq"           q-gcm.F:1265 */
+int qgcm_hip_atqzbd(qgcm_hip_handle h);     /* replaces "call atqzbd (qa, pa)"  q-gcm.F:1268 */
+/* boundary line sums of the last qgastep / cyclic qgostep, as the reference leaves them in MODULE athomog /
+ * ochomog: b = ajis, ajin, ap5s, ap5n (nlo each).  They are formed by the constraint kernel, i.e. valid after
+ * the atinvq / ocinvq that follows the step.  Synchronous. */
+int qgcm_hip_get_bsums(qgcm_hip_handle h, double *b);
+/* A coupled run with the forcing held between calls (xforc / oml / aml stay with the host):
+ * atmospheric steps nt = nt0 .. nt0+n-1 on `atm`, and on `oc` one ocean step before every atmospheric step with
+ * mod(nt,nstr) == 1 (src/q-gcm.F:1220-1268), each with its own averaging rule.  The two handles run on
+ * their own HIP streams, so the small atmospheric kernels overlap the ocean's. Either handle may be NULL. */
+int qgcm_hip_coupled_steps(qgcm_hip_handle oc, qgcm_hip_handle atm, int nt0, int n, int nstr);
 
 /* Helmholtz solve for homsol: wrk(nxpo,nypo) in/out, boc(nxto)
  * (replaces hsbxoc / hscyoc, src/ocisubs.F:415-618). Synchronous. */

@@ -18,12 +18,14 @@
 #    the reference (src/lasubs.f INCLUDEs an absent lapack/ dir); the
 #    image's MKL (/opt/conda/lib/libmkl_rt.so) provides it.
 #
-# usage: build_ref.sh <cfg> <nxta> <nyta> <nxaooc|nxta> <nyaooc> <ndxr> <nlo> <fnot> <beta> <cyclic 0|1> [extra cpp options]
+# usage: build_ref.sh <cfg> <nxta> <nyta> <nxaooc|nxta> <nyaooc> <ndxr> <nlo> <fnot> <beta> <cyclic 0|1> [extra cpp options] [coupled 0|1]
 #   extra cpp options: e.g. -Dsb_hflux (mixed-layer boundary variants, src/omlsubs.F:405-422,437-454);
 #   the cyclic builds carry -Dnb_hflux as examples/southern_ocean_ocean_only does
+#   coupled = 1: a coupled build (no -Docean_only, as examples/double_gyre_coupled/make.config.coupled):
+#   adds the atmosphere path qgasubs.F / atisubs.F / atqzbd and oracle/ref/qgcm_ref_atmos.F90
 set -euo pipefail
 
-CFG=$1; NXTA=$2; NYTA=$3; NXAOOC=$4; NYAOOC=$5; NDXR=$6; NLO=$7; FNOT=$8; BETA=$9; CYC=${10}; EXTRA=${11:-}
+CFG=$1; NXTA=$2; NYTA=$3; NXAOOC=$4; NYAOOC=$5; NDXR=$6; NLO=$7; FNOT=$8; BETA=$9; CYC=${10}; EXTRA=${11:-}; CPL=${12:-0}
 
 REF=${QGCM_REFERENCE:-/root/reference}
 SRC=$REF/src
@@ -49,18 +51,27 @@ sed -e "s|^      PARAMETER ( nxta = .*|      PARAMETER ( nxta = $NXTA, nyta = $N
     "$REF/examples/double_gyre_ocean_only/parameters_data.F.dg_oo" > parameters_data.F
 
 Q="-Docean_only"
-if [ "$CYC" = "1" ]; then Q="-Docean_only -Dcyclic_ocean -Dnb_hflux"; fi
+if [ "$CPL" = "1" ]; then Q=""; fi
+if [ "$CYC" = "1" ]; then Q="$Q -Dcyclic_ocean -Dnb_hflux"; fi
 Q="$Q $EXTRA"
 
 FCB="$FC -ffixed-line-length-132 -O2 -fPIC"
 FCO="$FCB -fopenmp"
 
 $FCO -c parameters_data.F
+ATMOBJ=""
+if [ "$CPL" = "1" ]; then
+  for f in atconst athomog atstate; do $FCO $Q -c -I"$SRC" "$SRC/${f}_data.F"; done
+  ATMOBJ="atconst_data.o athomog_data.o atstate_data.o atisubs.o qgasubs.o qgcm_ref_atmos.o"
+fi
 for f in occonst ochomog ocstate; do $FCO $Q -c -I"$SRC" "$SRC/${f}_data.F"; done
 $FCO -c -I"$SRC" "$SRC/monitor_data.F"
 $FCO -c -I"$SRC" "$SRC/intsubs.f"
 $FCO -c -I"$SRC" "$SRC/eigmode.f"
 ( cd "$SRC" && $FCO -c -o "$WRK/fftsubs.o" fftsubs.f ) 2> fftsubs.warn || { cat fftsubs.warn; exit 1; }
+if [ "$CPL" = "1" ]; then
+  for f in atisubs qgasubs; do $FCO $Q -c -I"$SRC" "$SRC/$f.F"; done
+fi
 for f in vorsubs qgosubs ocisubs conhoms; do $FCO $Q -c -I"$SRC" "$SRC/$f.F"; done
 # ocean mixed layer: intrfac / radiate data modules + omlsubs.F; the latter without
 # -fopenmp (flang rejects its REDUCTION(-:...) clause)
@@ -71,11 +82,12 @@ $FCB $Q -c -I"$SRC" "$SRC/omlsubs.F"
 $FCO $Q -c -I"$SRC" "$SRC/valsubs.F"
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_harness.F90"
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_oml.F90"
+if [ "$CPL" = "1" ]; then $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_atmos.F90"; fi
 
 $FC -shared -fopenmp -o "$OUT/libqgcm_ref_$CFG.so" \
     parameters_data.o occonst_data.o ochomog_data.o ocstate_data.o monitor_data.o \
     intsubs.o eigmode.o fftsubs.o vorsubs.o qgosubs.o ocisubs.o conhoms.o \
-    intrfac_data.o radiate_data.o omlsubs.o valsubs.o qgcm_ref_harness.o qgcm_ref_oml.o \
+    intrfac_data.o radiate_data.o omlsubs.o valsubs.o qgcm_ref_harness.o qgcm_ref_oml.o $ATMOBJ \
     -L"$MKLDIR" -Wl,--no-as-needed -lmkl_gf_lp64 -lmkl_sequential -lmkl_core -Wl,--as-needed -Wl,-rpath,"$MKLDIR" -Wl,-rpath,/opt/rocm/lib/llvm/lib
 
 echo "built $OUT/libqgcm_ref_$CFG.so"

@@ -32,6 +32,9 @@ def lib():
         dp = C.POINTER(C.c_double)
         L.qgo_create.restype = C.c_void_p
         L.qgo_create.argtypes = [C.c_int] * 4 + [C.c_double] * 6 + [dp] * 6
+        L.qgo_create_atmos.restype = C.c_void_p
+        L.qgo_create_atmos.argtypes = [C.c_int] * 3 + [C.c_double] * 5 + [dp] * 5
+        L.qgo_get_bsums.argtypes = [C.c_void_p, dp]
         L.qgo_xintp.restype = C.c_double
         L.qgo_xintp.argtypes = [dp, C.c_int, C.c_int]
         for name in ("qgo_destroy", "qgo_qgostep", "qgo_ocinvq", "qgo_ocqbdy", "qgo_lf_average"):
@@ -53,6 +56,7 @@ def lib():
         L.qgo_rfftf.argtypes = [C.c_int, dp]
         L.qgo_rfftb.argtypes = [C.c_int, dp]
         L.qgo_eigmod.argtypes = [C.c_int, dp, dp, C.c_double, dp, dp, dp, dp]
+        L.qgo_eigmod_atmos.argtypes = [C.c_int, dp, dp, C.c_double, dp, dp, dp, dp]
         L.qgo_wekpo_from_tau.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
         L.qgo_set_threads.argtypes = [C.c_int]
         L.qgo_oml_init.argtypes = [C.c_void_p] + [C.c_double] * 7 + [C.c_int, C.c_double, C.c_int, C.c_double]
@@ -98,7 +102,7 @@ def xintp(val):
     return lib().qgo_xintp(_dp(v), v.shape[0], v.shape[1])
 
 
-def eigmod(gpr, h, fnot):
+def eigmod(gpr, h, fnot, atmos=False):
     nl = len(h)
     g = np.ascontiguousarray(gpr, dtype=np.float64)
     hh = np.ascontiguousarray(h, dtype=np.float64)
@@ -106,7 +110,7 @@ def eigmod(gpr, h, fnot):
     cl2m = np.zeros((nl, nl), order="F")
     cm2l = np.zeros((nl, nl), order="F")
     rdm2 = np.zeros(nl)
-    lib().qgo_eigmod(nl, _dp(g), _dp(hh), fnot, _dp(amat), _dp(rdm2), _dp(cl2m), _dp(cm2l))
+    (lib().qgo_eigmod_atmos if atmos else lib().qgo_eigmod)(nl, _dp(g), _dp(hh), fnot, _dp(amat), _dp(rdm2), _dp(cl2m), _dp(cm2l))
     return dict(amatoc=amat, rdm2oc=rdm2, ctl2moc=cl2m, ctm2loc=cm2l)
 
 
@@ -280,3 +284,33 @@ class Oracle:
         b = np.ascontiguousarray(boc, dtype=np.float64)
         self.L.qgo_helmholtz(self.h, _dp(w), _dp(b))
         return w
+
+
+class AtmosOracle(Oracle):
+    """The atmospheric channel qgastep / atinvq / atqzbd - same call surface as
+    ref_binding.RefAtmos; the inherited names map as qgostep = qgastep, ocinvq = atinvq, ocqbdy = atqzbd."""
+
+    def __init__(self, nx, ny, nl, fnot, beta, dxa, dta, bccoat, ah4at, hat, gpat, yparel, ddynat=None):
+        self.nx, self.ny, self.nl, self.cyclic = nx, ny, nl, 1
+        self.fnot, self.beta = fnot, beta
+        a4 = np.ascontiguousarray(ah4at, dtype=np.float64)
+        h = np.ascontiguousarray(hat, dtype=np.float64)
+        g = np.ascontiguousarray(gpat, dtype=np.float64)
+        yp = np.ascontiguousarray(yparel, dtype=np.float64)
+        dd = np.zeros((nx, ny), order="F") if ddynat is None else np.asfortranarray(ddynat, dtype=np.float64)
+        self.L = lib()
+        self.h = self.L.qgo_create_atmos(nx, ny, nl, fnot, beta, dxa, dta, bccoat, _dp(a4), _dp(h), _dp(g), _dp(yp), _dp(dd))
+        self.nscal = 2 * (nl - 1) + 4 * nl
+
+    def set_forcing(self, wekpa, entat=None, xan=None, txis=0.0, txin=0.0, enis=None, enin=None):
+        Oracle.set_forcing(self, wekpa, entat, xan)
+        self.set_cyc_forcing(txis, txin, enis, enin)
+
+    def get_bsums(self):
+        b = np.zeros(4 * self.nl)
+        self.L.qgo_get_bsums(self.h, _dp(b))
+        return b
+
+    qgastep = Oracle.qgostep
+    atinvq = Oracle.ocinvq
+    atqzbd = Oracle.ocqbdy

@@ -21,6 +21,12 @@
 
 struct qgo_ctx {
   int nx, ny, nl, cyclic, nxt; /* nxt = nxto = nx-1 */
+  /* atmos = 1: the handle is the atmospheric channel (qgastep / atinvq / atqzbd): the cyclic
+   * code path with the atmosphere's conventions - layer 1 is the bottom layer (topography term in layer 1),
+   * forcing signs of src/qgasubs.F:128-131, no drag / Del-4th terms, constraint right-hand sides of
+   * src/atisubs.F:177-196, dpiat = integral of pa(k)-pa(k+1), averaging every 100 steps.  The member names stay
+   * the ocean's (po = pa, ocncs = atmcs, ...). */
+  int atmos;
   double fnot, beta, dxo, dyo, dxom2, dto, tdto, delek, bccooc, xlo, ylo;
   double *ah2oc, *ah4oc, *hoc, *gpoc, *yporel, *ddynoc;
   double *amatoc, *ctl2moc, *ctm2loc, *rdm2oc; /* (nl,nl) Fortran order */
@@ -361,7 +367,7 @@ double qgo_xintp(const double *valp, int nx, int ny) {
 /* follow from a symmetric Jacobi solve of H^-1/2 T H^-1/2 (SURVEY      */
 /* appendix A).  Normalisation/sign/sort follow eigmode.f:310-428.      */
 /* ------------------------------------------------------------------ */
-void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
+static void eigmod_impl(int atmos, int nl, const double *gpr, const double *h, double fnot,
                 double *aaa, double *rdm2, double *ctl2m, double *ctm2l) {
   double *S = dalloc((size_t)nl * nl), *V = dalloc((size_t)nl * nl), *lam = dalloc(nl);
 #define A_(r, c) aaa[((r)-1) + nl * ((c)-1)]
@@ -438,6 +444,15 @@ void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
     for (int k = 1; k <= nl; ++k) { R[k - 1] = V_(k, im) / sqrt(h[k - 1]); dotp += h[k - 1] * R[k - 1] * R[k - 1]; }
     double fl = sqrt(htotal / dotp);
     if (R[0] < 0.0) fl = -fl;
+    if (atmos) {
+      /* case 'Atmosphere': no Flierl normalisation (eigmode.f:309); the right eigenvectors stay as LAPACK's DTREVC
+       * leaves them, i.e. scaled so that the component of largest magnitude has magnitude 1 (eigmode.f:283-296). Their
+       * sign comes out of the Schur vectors and cannot be restated; positive at k = 1 reproduces the reference for the
+       * example configurations, and pa, qa do not depend on scale or sign of a mode (cm2l * cl2m = 1). */
+      double mx = 0.0;
+      for (int k = 0; k < nl; ++k) mx = fmax(mx, fabs(R[k]));
+      fl = ((R[0] < 0.0) ? -1.0 : 1.0) / mx;
+    }
     for (int k = 1; k <= nl; ++k) R[k - 1] *= fl;
     /* left eigenvector L = H R (up to scale): cl2m(m,k) = L(k)/(L.R)  (eigmode.f:420-428) */
     double LR = 0.0;
@@ -452,6 +467,15 @@ void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
 #undef A_
 #undef S_
 #undef V_
+}
+
+void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
+                double *amat, double *rdm2, double *ctl2m, double *ctm2l) {
+  eigmod_impl(0, nl, gpr, h, fnot, amat, rdm2, ctl2m, ctm2l);
+}
+void qgo_eigmod_atmos(int nl, const double *gpr, const double *h, double fnot,
+                      double *amat, double *rdm2, double *ctl2m, double *ctm2l) {
+  eigmod_impl(1, nl, gpr, h, fnot, amat, rdm2, ctl2m, ctm2l);
 }
 
 /* ------------------------------------------------------------------ */
@@ -605,6 +629,9 @@ static void homsol(qgo_ctx *c) {
       /* ypo(nypo)-ypo(j) = (nypo-j)*dyo ; conhoms.F:424-431 */
       for (int j = 1; j <= ny; ++j) {
         double ypoj = c->yporel[j - 1], ypon = c->yporel[ny - 1], ypo1 = c->yporel[0];
+        if (c->atmos) { /* conhoms.F:664-665 uses ypa(j) = (j-1)*dya itself, src/q-gcm.F:402 */
+          ypoj = (j - 1) * c->dyo; ypon = (ny - 1) * c->dyo; ypo1 = 0 * c->dyo;
+        }
         p1[j - 1] = (ypon - ypoj) / c->ylo;
         p2[j - 1] = (ypoj - ypo1) / c->ylo;
         for (int i = 1; i <= nx; ++i) { w1[IX(i, j)] = p1[j - 1]; w2[IX(i, j)] = p2[j - 1]; }
@@ -661,12 +688,13 @@ static void homsol(qgo_ctx *c) {
 }
 
 /* ------------------------------------------------------------------ */
-qgo_ctx *qgo_create(int nxpo, int nypo, int nlo, int cyclic, double fnot, double beta,
+static qgo_ctx *create_impl(int nxpo, int nypo, int nlo, int cyclic, double fnot, double beta,
                     double dxo, double dto, double delek, double bccooc,
                     const double *ah2oc, const double *ah4oc, const double *hoc,
-                    const double *gpoc, const double *yporel, const double *ddynoc) {
+                    const double *gpoc, const double *yporel, const double *ddynoc, int atmos) {
   qgo_ctx *c = (qgo_ctx *)calloc(1, sizeof(qgo_ctx));
   int nx = nxpo, ny = nypo, nl = nlo;
+  c->atmos = atmos;
   c->nx = nx; c->ny = ny; c->nl = nl; c->cyclic = cyclic; c->nxt = nx - 1;
   c->fnot = fnot; c->beta = beta; c->dxo = dxo; c->dyo = dxo; c->dxom2 = 1.0 / (dxo * dxo);
   c->dto = dto; c->tdto = 2.0 * dto; c->delek = delek; c->bccooc = bccooc;
@@ -680,7 +708,7 @@ qgo_ctx *qgo_create(int nxpo, int nypo, int nlo, int cyclic, double fnot, double
   if (ddynoc) memcpy(c->ddynoc, ddynoc, sizeof(double) * N);
   c->amatoc = dalloc((size_t)nl * nl); c->ctl2moc = dalloc((size_t)nl * nl);
   c->ctm2loc = dalloc((size_t)nl * nl); c->rdm2oc = dalloc(nl);
-  qgo_eigmod(nl, c->gpoc, c->hoc, fnot, c->amatoc, c->rdm2oc, c->ctl2moc, c->ctm2loc);
+  eigmod_impl(atmos, nl, c->gpoc, c->hoc, fnot, c->amatoc, c->rdm2oc, c->ctl2moc, c->ctm2loc);
   /* src/q-gcm.F:932-954 */
   int nxt = c->nxt;
   c->aoc = 1.0 / (c->dyo * c->dyo);
@@ -714,6 +742,22 @@ qgo_ctx *qgo_create(int nxpo, int nypo, int nlo, int cyclic, double fnot, double
   c->d2p = dalloc(N); c->d4p = dalloc(N); c->dqdt = dalloc(N * nl); c->wrk = dalloc(N * nl);
   homsol(c);
   return c;
+}
+
+qgo_ctx *qgo_create(int nxpo, int nypo, int nlo, int cyclic, double fnot, double beta,
+                    double dxo, double dto, double delek, double bccooc,
+                    const double *ah2oc, const double *ah4oc, const double *hoc,
+                    const double *gpoc, const double *yporel, const double *ddynoc) {
+  return create_impl(nxpo, nypo, nlo, cyclic, fnot, beta, dxo, dto, delek, bccooc, ah2oc, ah4oc, hoc, gpoc, yporel,
+                     ddynoc, 0);
+}
+
+/* the atmospheric channel: grid (nxpa, nypa, nla), dxa, dta, bccoat, ah4at, hat, gpat, yparel, ddynat */
+qgo_ctx *qgo_create_atmos(int nxpa, int nypa, int nla, double fnot, double beta, double dxa, double dta,
+                          double bccoat, const double *ah4at, const double *hat, const double *gpat,
+                          const double *yparel, const double *ddynat) {
+  double zero[64] = {0};
+  return create_impl(nxpa, nypa, nla, 1, fnot, beta, dxa, dta, 0.0, bccoat, zero, ah4at, hat, gpat, yparel, ddynat, 1);
 }
 
 void qgo_destroy(qgo_ctx *c) {
@@ -754,8 +798,9 @@ static void qcomp(qgo_ctx *c, double *q, const double *p) {
       }
     }
   }
+  const int kt = c->atmos ? 1 : nl; /* layer that feels the topography: last argument of qcomp, src/q-gcm.F:719-741 */
   for (int j = 2; j <= ny - 1; ++j)
-    for (int i = 2; i <= nx - 1; ++i) q[IX3(i, j, nl)] = q[IX3(i, j, nl)] + c->ddynoc[IX(i, j)];
+    for (int i = 2; i <= nx - 1; ++i) q[IX3(i, j, kt)] = q[IX3(i, j, kt)] + c->ddynoc[IX(i, j)];
 }
 
 static void merqcy(qgo_ctx *c, double *q, const double *p) {
@@ -775,14 +820,50 @@ static void merqcy(qgo_ctx *c, double *q, const double *p) {
       q[IX3(1, j, k)] = lap - fnot * ap;
       q[IX3(nx, j, k)] = q[IX3(1, j, k)];
     }
+  const int kt = c->atmos ? 1 : nl;
   for (int j = 2; j <= ny - 1; ++j) {
-    q[IX3(1, j, nl)] = q[IX3(1, j, nl)] + c->ddynoc[IX(1, j)];
-    q[IX3(nx, j, nl)] = q[IX3(1, j, nl)];
+    q[IX3(1, j, kt)] = q[IX3(1, j, kt)] + c->ddynoc[IX(1, j)];
+    q[IX3(nx, j, kt)] = q[IX3(1, j, kt)];
+  }
+}
+
+/* atqzbd: src/vorsubs.F:396-480.  Zonal boundaries only; topography in layer 1.  The southern value of the top
+ * layer reads pa(i,2,nla) where every other layer reads the boundary point pa(i,1,k) (src/vorsubs.F:470) - kept
+ * as written, the reference's results depend on it. */
+static void atqzbd(qgo_ctx *c, double *qa, const double *pa) {
+  int nx = c->nx, ny = c->ny, nl = c->nl;
+  double fnot = c->fnot;
+  const double *aaa = c->amatoc;
+  double zbfaca = c->bccooc * c->dxom2 / (0.5 * c->bccooc + 1.0) / fnot;
+  double betays = c->beta * c->yporel[0], betayn = c->beta * c->yporel[ny - 1];
+  double f0Ac = fnot * M2(aaa, 1, 1), f0Ap = fnot * M2(aaa, 1, 2), f0Am;
+  for (int i = 1; i <= nx; ++i) {
+    qa[IX3(i, 1, 1)] = zbfaca * (pa[IX3(i, 2, 1)] - pa[IX3(i, 1, 1)]) - (f0Ac * pa[IX3(i, 1, 1)] + f0Ap * pa[IX3(i, 1, 2)]) +
+                       betays + c->ddynoc[IX(i, 1)];
+    qa[IX3(i, ny, 1)] = zbfaca * (pa[IX3(i, ny - 1, 1)] - pa[IX3(i, ny, 1)]) -
+                        (f0Ac * pa[IX3(i, ny, 1)] + f0Ap * pa[IX3(i, ny, 2)]) + betayn + c->ddynoc[IX(i, ny)];
+  }
+  for (int k = 2; k <= nl - 1; ++k) {
+    f0Am = fnot * M2(aaa, k, k - 1); f0Ac = fnot * M2(aaa, k, k); f0Ap = fnot * M2(aaa, k, k + 1);
+    for (int i = 1; i <= nx; ++i) {
+      qa[IX3(i, 1, k)] = zbfaca * (pa[IX3(i, 2, k)] - pa[IX3(i, 1, k)]) -
+                         (f0Am * pa[IX3(i, 1, k - 1)] + f0Ac * pa[IX3(i, 1, k)] + f0Ap * pa[IX3(i, 1, k + 1)]) + betays;
+      qa[IX3(i, ny, k)] = zbfaca * (pa[IX3(i, ny - 1, k)] - pa[IX3(i, ny, k)]) -
+                          (f0Am * pa[IX3(i, ny, k - 1)] + f0Ac * pa[IX3(i, ny, k)] + f0Ap * pa[IX3(i, ny, k + 1)]) + betayn;
+    }
+  }
+  f0Am = fnot * M2(aaa, nl, nl - 1); f0Ac = fnot * M2(aaa, nl, nl);
+  for (int i = 1; i <= nx; ++i) {
+    qa[IX3(i, 1, nl)] = zbfaca * (pa[IX3(i, 2, nl)] - pa[IX3(i, 1, nl)]) -
+                        (f0Am * pa[IX3(i, 1, nl - 1)] + f0Ac * pa[IX3(i, 2, nl)]) + betays; /* sic: row 2, vorsubs.F:470 */
+    qa[IX3(i, ny, nl)] = zbfaca * (pa[IX3(i, ny - 1, nl)] - pa[IX3(i, ny, nl)]) -
+                         (f0Am * pa[IX3(i, ny, nl - 1)] + f0Ac * pa[IX3(i, ny, nl)]) + betayn;
   }
 }
 
 /* ocqbdy: src/vorsubs.F:245-388 */
 static void ocqbdy(qgo_ctx *c, double *qo, const double *po) {
+  if (c->atmos) { atqzbd(c, qo, po); return; }
   int nx = c->nx, ny = c->ny, nl = c->nl;
   double fnot = c->fnot;
   const double *aaa = c->amatoc;
@@ -825,6 +906,12 @@ static void constr(qgo_ctx *c) {
   size_t N = (size_t)nx * ny;
   double *w1 = c->d2p, *w2 = c->d4p;
   for (int k = 1; k <= nl - 1; ++k) {
+    if (c->atmos) /* dpiat: pa(k) - pa(k+1), conhoms.F:205-216 */
+      for (size_t t = 0; t < N; ++t) {
+        w1[t] = c->pom[t + N * (k - 1)] - c->pom[t + N * k];
+        w2[t] = c->po[t + N * (k - 1)] - c->po[t + N * k];
+      }
+    else
     for (size_t t = 0; t < N; ++t) {
       w1[t] = c->pom[t + N * k] - c->pom[t + N * (k - 1)];
       w2[t] = c->po[t + N * k] - c->po[t + N * (k - 1)];
@@ -933,6 +1020,14 @@ void qgo_set_scalars(qgo_ctx *c, const double *s) {
       c->ocncs[k] = s[o + k]; c->ocncn[k] = s[o + nl + k];
       c->ocncsp[k] = s[o + 2 * nl + k]; c->ocncnp[k] = s[o + 3 * nl + k];
     }
+}
+
+/* boundary line sums of the last qgostep (cyclic / atmosphere): ajis, ajin, ap5s, ap5n (nl each) */
+void qgo_get_bsums(qgo_ctx *c, double *b) {
+  for (int k = 0; k < c->nl; ++k) {
+    b[k] = c->ajisoc[k]; b[c->nl + k] = c->ajinoc[k];
+    b[2 * c->nl + k] = c->ap5soc[k]; b[3 * c->nl + k] = c->ap5noc[k];
+  }
 }
 
 void qgo_get_inv_diag(qgo_ctx *c, double *xinhom, double *coef) {
@@ -1062,6 +1157,16 @@ static void ocadif(qgo_ctx *c, int k, double *dqdt, const double *d2p, double ah
     aj9 = aj9 - 0.5 * q[IX(nx, ny - 1)] * (p[IX(2, ny - 1)] - p[IX(nx - 1, ny - 1)]);
     c->ajinoc[k - 1] = c->dxo * c->dyo * (fnot * adfaco * (aj5 + 2.0 * aj9));
     double ah3s = 0, ah3n = 0, ah5s = 0, ah5n = 0;
+    if (c->atmos) { /* atadif: trapezoid over i = 1..nxpa, no Del-4th (ah2) term: src/qgasubs.F:305-314 */
+      ah5s = 0.5 * (d4p[IX(1, 2)] - d4p[IX(1, 1)]);
+      ah5n = 0.5 * (d4p[IX(1, ny)] - d4p[IX(1, ny - 1)]);
+      for (int i = 2; i <= nx - 1; ++i) {
+        ah5s = ah5s + (d4p[IX(i, 2)] - d4p[IX(i, 1)]);
+        ah5n = ah5n + (d4p[IX(i, ny)] - d4p[IX(i, ny - 1)]);
+      }
+      ah5s = ah5s + 0.5 * (d4p[IX(nx, 2)] - d4p[IX(nx, 1)]);
+      ah5n = ah5n + 0.5 * (d4p[IX(nx, ny)] - d4p[IX(nx, ny - 1)]);
+    } else
     for (int i = 1; i <= nx - 1; ++i) {
       ah3s = ah3s + (d2p[IX(i, 2)] - d2p[IX(i, 1)]);
       ah3n = ah3n + (d2p[IX(i, ny)] - d2p[IX(i, ny - 1)]);
@@ -1106,7 +1211,7 @@ void qgo_qgostep(qgo_ctx *c) {
     ocadif(c, k, c->dqdt + N * (k - 1), del2p, c->ah2oc[k - 1], c->ah4oc[k - 1], bcfaco,
            c->po + N * (k - 1), c->qo + N * (k - 1), adfaco);
   }
-  if (cyc) { /* qgosubs.F:150-163 */
+  if (cyc && !c->atmos) { /* qgosubs.F:150-163 */
     double bds = 0.0, bdn = 0.0;
     for (int i = 1; i <= nx - 1; ++i) {
       bds = bds + (pom[IX3(i, 2, nl)] - pom[IX3(i, 1, nl)]);
@@ -1121,10 +1226,16 @@ void qgo_qgostep(qgo_ctx *c) {
   for (int j = 2; j <= ny - 1; ++j)
     for (int i = 1; i <= nx; ++i) {
       double qdot[64];
+      if (c->atmos) { /* src/qgasubs.F:128-134: entrainment and Ekman pumping act from below, no drag */
+        qdot[0] = c->dqdt[IX3(i, j, 1)] + fohfac[0] * (c->entoc[IX(i, j)] - c->wekpo[IX(i, j)]);
+        qdot[1] = c->dqdt[IX3(i, j, 2)] - fohfac[1] * c->entoc[IX(i, j)];
+        for (int k = 3; k <= nl; ++k) qdot[k - 1] = c->dqdt[IX3(i, j, k)];
+      } else {
       qdot[0] = c->dqdt[IX3(i, j, 1)] + fohfac[0] * (c->wekpo[IX(i, j)] - c->entoc[IX(i, j)]);
       qdot[1] = c->dqdt[IX3(i, j, 2)] + fohfac[1] * c->entoc[IX(i, j)];
       for (int k = 3; k <= nl; ++k) qdot[k - 1] = c->dqdt[IX3(i, j, k)];
       qdot[nl - 1] = qdot[nl - 1] - bdrfac * del2p[IX(i, j)];
+      }
       for (int k = 1; k <= nl; ++k) {
         double qold = c->qo[IX3(i, j, k)];
         c->qo[IX3(i, j, k)] = c->qom[IX3(i, j, k)] + tdto * qdot[k - 1];
@@ -1147,7 +1258,8 @@ void qgo_project(qgo_ctx *c, double *wrk) {
     for (int i = 1; i <= nx; ++i) {
       double ql[64];
       for (int k = 1; k <= nl; ++k) ql[k - 1] = c->qo[IX3(i, j, k)] - betay;
-      ql[nl - 1] = ql[nl - 1] - c->ddynoc[IX(i, j)];
+      if (c->atmos) ql[0] = ql[0] - c->ddynoc[IX(i, j)]; /* src/atisubs.F:117 */
+      else ql[nl - 1] = ql[nl - 1] - c->ddynoc[IX(i, j)];
       for (int m = 1; m <= nl; ++m) {
         double qm = 0.0;
         for (int k = 1; k <= nl; ++k) qm = qm + M2(c->ctl2moc, k, m) * ql[k - 1];
@@ -1179,6 +1291,16 @@ void qgo_ocinvq(qgo_ctx *c) {
     double aipmod[64], aiplay[64];
     const double *hoc = c->hoc;
     double entfac = 0.5 * dyo * fnot * fnot;
+    if (c->atmos) { /* src/atisubs.F:177-196: layer 1 is the bottom layer, stress enters with the opposite sign */
+      rhss[0] = -(entfac / hoc[0]) * c->enisoc[0] - (fnot / hoc[0]) * c->txisoc + c->ajisoc[0] + c->ap5soc[0];
+      rhsn[0] = -(entfac / hoc[0]) * c->eninoc[0] + (fnot / hoc[0]) * c->txinoc + c->ajinoc[0] - c->ap5noc[0];
+      for (int k = 2; k <= nl - 1; ++k) {
+        rhss[k - 1] = -(entfac / hoc[k - 1]) * (c->enisoc[k - 1] - c->enisoc[k - 2]) + c->ajisoc[k - 1] + c->ap5soc[k - 1];
+        rhsn[k - 1] = -(entfac / hoc[k - 1]) * (c->eninoc[k - 1] - c->eninoc[k - 2]) + c->ajinoc[k - 1] - c->ap5noc[k - 1];
+      }
+      rhss[nl - 1] = (entfac / hoc[nl - 1]) * c->enisoc[nl - 2] + c->ajisoc[nl - 1] + c->ap5soc[nl - 1];
+      rhsn[nl - 1] = (entfac / hoc[nl - 1]) * c->eninoc[nl - 2] + c->ajinoc[nl - 1] - c->ap5noc[nl - 1];
+    } else {
     /* ocisubs.F:176-193 */
     rhss[0] = (entfac / hoc[0]) * c->enisoc[0] + (fnot / hoc[0]) * c->txisoc + c->ajisoc[0] - c->ap3soc[0] + c->ap5soc[0];
     rhsn[0] = (entfac / hoc[0]) * c->eninoc[0] - (fnot / hoc[0]) * c->txinoc + c->ajinoc[0] + c->ap3noc[0] - c->ap5noc[0];
@@ -1188,6 +1310,7 @@ void qgo_ocinvq(qgo_ctx *c) {
     }
     rhss[nl - 1] = -(entfac / hoc[nl - 1]) * c->enisoc[nl - 2] + c->ajisoc[nl - 1] - c->ap3soc[nl - 1] + c->ap5soc[nl - 1] + (fnot / hoc[nl - 1]) * c->bdrins;
     rhsn[nl - 1] = -(entfac / hoc[nl - 1]) * c->eninoc[nl - 2] + c->ajinoc[nl - 1] + c->ap3noc[nl - 1] - c->ap5noc[nl - 1] - (fnot / hoc[nl - 1]) * c->bdrinn;
+    }
     for (int k = 0; k < nl; ++k) { /* ocisubs.F:199-206 */
       ocsnew[k] = c->ocncsp[k] + tdto * rhss[k];
       ocnnew[k] = c->ocncnp[k] + tdto * rhsn[k];
@@ -1223,7 +1346,7 @@ void qgo_ocinvq(qgo_ctx *c) {
     }
     for (int k = 1; k <= nl - 1; ++k) { /* ocisubs.F:268-294 (monitors omitted) */
       c->dpiocp[k - 1] = c->dpioc[k - 1];
-      c->dpioc[k - 1] = aiplay[k] - aiplay[k - 1];
+      c->dpioc[k - 1] = c->atmos ? aiplay[k - 1] - aiplay[k] /* atisubs.F:256 */ : aiplay[k] - aiplay[k - 1];
     }
     for (int m = 0; m < nl - 1; ++m) { c->invcoef[m] = c1[m]; c->invcoef[nl - 1 + m] = c2[m]; }
     c->invcoef[2 * (nl - 1)] = c3;
@@ -1302,7 +1425,8 @@ void qgo_steps(qgo_ctx *c, int s0, int n) {
     qgo_qgostep(c);
     qgo_ocinvq(c);
     qgo_ocqbdy(c);
-    if ((s - 1) % 25 == 0) qgo_lf_average(c);
+    /* the atmosphere is averaged when mod(nt-1,100) == 0, nt = its own step count (src/q-gcm.F:1370) */
+    if ((s - 1) % (c->atmos ? 100 : 25) == 0) qgo_lf_average(c);
   }
 }
 

@@ -34,6 +34,15 @@ qgo_ctx *qgo_create(int nxpo, int nypo, int nlo, int cyclic,
                     const double *ah2oc, const double *ah4oc,
                     const double *hoc, const double *gpoc,
                     const double *yporel, const double *ddynoc);
+/* The atmospheric channel of a coupled run: qgastep / atinvq / atqzbd
+ * (src/qgasubs.F:45-317, src/atisubs.F:60-395, src/vorsubs.F:396-480) behind the same entry points -
+ * qgo_qgostep = qgastep, qgo_ocinvq = atinvq, qgo_ocqbdy = atqzbd, qgo_set_p = constr + qcomp + atqzbd + merqcy,
+ * qgo_steps averages when mod(nt-1,100) == 0 (src/q-gcm.F:1370), qgo_set_cyc_forcing takes txisat/txinat,
+ * enisat/eninat, qgo_set_forcing wekpa/entat/xan, the scalars are dpiat, dpiatp, atmcs, atmcn, atmcsp, atmcnp.
+ * Pinned by tests/golden/atm_*.npz from a coupled build of the reference. */
+qgo_ctx *qgo_create_atmos(int nxpa, int nypa, int nla, double fnot, double beta, double dxa, double dta,
+                          double bccoat, const double *ah4at, const double *hat, const double *gpat,
+                          const double *yparel, const double *ddynat);
 void qgo_destroy(qgo_ctx *c);
 void qgo_set_threads(int nthreads);
 
@@ -48,6 +57,8 @@ void qgo_get_scalars(qgo_ctx *c, double *scal);
 void qgo_set_scalars(qgo_ctx *c, const double *scal);
 /* diagnostics of the last ocinvq: xinhom(nlo), then hclco(nlo-1) [box] or c1(nlo-1),c2(nlo-1),c3 [cyclic] */
 void qgo_get_inv_diag(qgo_ctx *c, double *xinhom, double *coef);
+/* cyclic / atmosphere: boundary line sums of the last qgostep - ajis, ajin, ap5s, ap5n (nlo each) */
+void qgo_get_bsums(qgo_ctx *c, double *b);
 
 /* constants */
 void qgo_get_consts(qgo_ctx *c, double *amatoc, double *ctl2moc, double *ctm2loc,
@@ -73,6 +84,9 @@ void qgo_rfftf(int n, double *x);                           /* FFTPACK half-comp
 void qgo_rfftb(int n, double *x);
 void qgo_eigmod(int nl, const double *gpr, const double *h, double fnot,
                 double *amat, double *rdm2, double *ctl2m, double *ctm2l);
+/* eigmod with case = 'Atmosphere' (no Flierl normalisation, eigmode.f:309): see the note in qgcm_oracle.c */
+void qgo_eigmod_atmos(int nl, const double *gpr, const double *h, double fnot,
+                      double *amat, double *rdm2, double *ctl2m, double *ctm2l);
 /* ocean-only Ekman pumping from wind stress, xfosubs.F:138,566-645 */
 void qgo_wekpo_from_tau(int nxpo, int nypo, int cyclic, double dxo, double fnot,
                         const double *tauxo, const double *tauyo, double *wekto, double *wekpo);

@@ -169,8 +169,11 @@ contains
     call dsinti (nxto-1, oftwrk)
 #endif
 
-    ! src/q-gcm.F:976
+    ! src/q-gcm.F:976.  In a coupled build homsol also does the atmosphere, whose constants
+    ! ref_atm_init sets: there the caller runs ref_homsol after both initialisations.
+#ifdef ocean_only
     call homsol
+#endif
   end subroutine ref_init
 
   ! Load pressures, then derive q and the constraint scalars exactly as

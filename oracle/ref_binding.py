@@ -31,6 +31,12 @@ CONFIGS = {
     "cyc_small": (6, 10, "nxta", 4, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
     "box_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0),
     "cyc_socn5": (288, 108, "nxta", 36, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
+    # coupled builds (no -Docean_only; -Dsb_hflux as examples/double_gyre_coupled/make.config.coupled): the ocean
+    # path as above + the atmosphere path qgastep/atinvq/atqzbd.  Atmosphere (nxta+1, nyta+1, 3):
+    # cpl_tiny 17x13 over the box_tiny ocean, cpl_small 33x21, cpl_natl5 = examples/double_gyre_coupled (385x97).
+    "cpl_tiny": (16, 12, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsb_hflux", 1),
+    "cpl_small": (32, 20, 6, 5, 16, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsb_hflux", 1),
+    "cpl_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsb_hflux", 1),
 }
 
 
@@ -302,3 +308,126 @@ class RefLib:
         self.lib.ref_eigmod.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
         self.lib.ref_eigmod(nl, _dp(g), _dp(hh), _dp(amat), _dp(rdm2), _dp(cl2m), _dp(cm2l))
         return dict(amatoc=amat, rdm2oc=rdm2, ctl2moc=cl2m, ctm2loc=cm2l)
+
+
+class RefAtmos:
+    """Atmosphere half (qgastep / atinvq / atqzbd) of a *coupled* reference build
+    (CONFIGS "cpl_*"); shares the process-wide library with RefLib(cfg).  Arrays (nxpa, nypa, nla)."""
+
+    def __init__(self, ref):
+        self.ref = ref
+        self.lib = ref.lib
+        nx, ny, nl = C.c_int(), C.c_int(), C.c_int()
+        self.lib.ref_atm_dims(C.byref(nx), C.byref(ny), C.byref(nl))
+        self.nx, self.ny, self.nl = nx.value, ny.value, nl.value
+        self.fnot, self.beta = ref.fnot, ref.beta
+        self.nscal = 2 * (self.nl - 1) + 4 * self.nl
+
+    def _f3(self):
+        return np.zeros((self.nx, self.ny, self.nl), order="F")
+
+    def _f2(self):
+        return np.zeros((self.nx, self.ny), order="F")
+
+    def init(self, dxa, dta, bccoat, ah4at, hat, gpat, ddynat=None):
+        a4 = np.ascontiguousarray(ah4at, dtype=np.float64)
+        h = np.ascontiguousarray(hat, dtype=np.float64)
+        g = np.ascontiguousarray(gpat, dtype=np.float64)
+        dd = self._f2() if ddynat is None else np.asfortranarray(ddynat, dtype=np.float64)
+        self.lib.ref_atm_init.argtypes = [C.c_double] * 3 + [C.POINTER(C.c_double)] * 4
+        run_big_stack(self.lib.ref_atm_init, dxa, dta, bccoat, _dp(a4), _dp(h), _dp(g), _dp(dd))
+
+    def homsol(self):
+        """homsol of the coupled build: ocean AND atmosphere (both must be initialised)."""
+        run_big_stack(self.lib.ref_homsol)
+
+    def set_p(self, pa, pam):
+        pa = np.asfortranarray(pa, dtype=np.float64)
+        pam = np.asfortranarray(pam, dtype=np.float64)
+        run_big_stack(self.lib.ref_atm_set_p, _dp(pa), _dp(pam))
+
+    def set_state(self, pa, pam, qa, qam):
+        a = [np.asfortranarray(x, dtype=np.float64) for x in (pa, pam, qa, qam)]
+        self.lib.ref_atm_set_state(*[_dp(x) for x in a])
+
+    def get_state(self):
+        a = [self._f3() for _ in range(4)]
+        self.lib.ref_atm_get_state(*[_dp(x) for x in a])
+        return a
+
+    def set_forcing(self, wekpa, entat=None, xan=None, txis=0.0, txin=0.0, enis=None, enin=None):
+        w = np.asfortranarray(wekpa, dtype=np.float64)
+        e = self._f2() if entat is None else np.asfortranarray(entat, dtype=np.float64)
+
+        def z(v):
+            return np.zeros(self.nl - 1) if v is None else np.ascontiguousarray(v, dtype=np.float64)
+        x, es, en = z(xan), z(enis), z(enin)
+        self.lib.ref_atm_set_forcing.argtypes = ([C.POINTER(C.c_double)] * 3 + [C.c_double] * 2 +
+                                                 [C.POINTER(C.c_double)] * 2)
+        self.lib.ref_atm_set_forcing(_dp(w), _dp(e), _dp(x), float(txis), float(txin), _dp(es), _dp(en))
+
+    def get_scalars(self):
+        s = np.zeros(self.nscal)
+        self.lib.ref_atm_get_scalars(_dp(s))
+        return s
+
+    def set_scalars(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        self.lib.ref_atm_set_scalars(_dp(s))
+
+    def get_bsums(self):
+        """ajisat, ajinat, ap5sat, ap5nat (nla each) of the last qgastep."""
+        b = np.zeros(4 * self.nl)
+        self.lib.ref_atm_get_bsums(_dp(b))
+        return b
+
+    def get_consts(self):
+        nl = self.nl
+        amat = np.zeros((nl, nl), order="F")
+        cl2m = np.zeros((nl, nl), order="F")
+        cm2l = np.zeros((nl, nl), order="F")
+        rdm2 = np.zeros(nl)
+        bd2 = np.zeros(self.nx - 1)
+        ypr = np.zeros(self.ny)
+        aat = C.c_double()
+        self.lib.ref_atm_get_consts(_dp(amat), _dp(cl2m), _dp(cm2l), _dp(rdm2), _dp(bd2), _dp(ypr), C.byref(aat))
+        return dict(amatat=amat, ctl2mat=cl2m, ctm2lat=cm2l, rdm2at=rdm2, bd2at=bd2, yparel=ypr, aat=aat.value)
+
+    def get_homog(self):
+        nl, ny = self.nl, self.ny
+        hom = np.zeros(ny * (2 * (nl - 1) + 1))
+        aux = np.zeros(5 * (nl - 1) + 2)
+        self.lib.ref_atm_get_homog(_dp(hom), _dp(aux))
+        n1 = ny * (nl - 1)
+        return dict(pch1at=hom[:n1].reshape((ny, nl - 1), order="F").copy(order="F"),
+                    pch2at=hom[n1:2 * n1].reshape((ny, nl - 1), order="F").copy(order="F"),
+                    pbhat=hom[2 * n1:].copy(),
+                    aipcha=aux[0:nl - 1].copy(), hc1sat=aux[nl - 1:2 * (nl - 1)].copy(),
+                    hc2sat=aux[2 * (nl - 1):3 * (nl - 1)].copy(), hc1nat=aux[3 * (nl - 1):4 * (nl - 1)].copy(),
+                    hc2nat=aux[4 * (nl - 1):5 * (nl - 1)].copy(), hbsiat=aux[5 * (nl - 1)], aipbha=aux[5 * (nl - 1) + 1])
+
+    def qgastep(self):
+        run_big_stack(self.lib.ref_qgastep)
+
+    def atinvq(self):
+        run_big_stack(self.lib.ref_atinvq)
+
+    def atqzbd(self):
+        run_big_stack(self.lib.ref_atqzbd)
+
+    def lf_average(self):
+        self.lib.ref_atm_lf_average()
+
+    def steps(self, nt0, n):
+        self.lib.ref_atm_steps.argtypes = [C.c_int, C.c_int]
+        run_big_stack(self.lib.ref_atm_steps, int(nt0), int(n))
+
+    def coupled_steps(self, nt0, n, nstr):
+        self.lib.ref_coupled_steps.argtypes = [C.c_int, C.c_int, C.c_int]
+        run_big_stack(self.lib.ref_coupled_steps, int(nt0), int(n), int(nstr))
+
+    def helmholtz(self, wrk, bat):
+        w = np.asfortranarray(wrk, dtype=np.float64).copy(order="F")
+        b = np.ascontiguousarray(bat, dtype=np.float64)
+        run_big_stack(self.lib.ref_atm_helmholtz, _dp(w), _dp(b))
+        return w

@@ -160,6 +160,19 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
     xin[m] = s[m] * P.dxo * P.dyo;
     sc->xinhom[m] = xin[m];
   }
+  if (P.g.atm) {
+    // atmosphere, src/atisubs.F:177-196: layer 1 is the bottom layer (stress and entrainment enter with the
+    // opposite sign), no Del-4th and no drag terms
+    rhss[0] = -(entfac / P.hoc[0]) * sc->enisoc[0] - (fnot / P.hoc[0]) * sc->txisoc + sc->ajisoc[0] + sc->ap5soc[0];
+    rhsn[0] = -(entfac / P.hoc[0]) * sc->eninoc[0] + (fnot / P.hoc[0]) * sc->txinoc + sc->ajinoc[0] - sc->ap5noc[0];
+#pragma unroll
+    for (int k = 1; k < NL - 1; ++k) {
+      rhss[k] = -(entfac / P.hoc[k]) * (sc->enisoc[k] - sc->enisoc[k - 1]) + sc->ajisoc[k] + sc->ap5soc[k];
+      rhsn[k] = -(entfac / P.hoc[k]) * (sc->eninoc[k] - sc->eninoc[k - 1]) + sc->ajinoc[k] - sc->ap5noc[k];
+    }
+    rhss[NL - 1] = (entfac / P.hoc[NL - 1]) * sc->enisoc[NL - 2] + sc->ajisoc[NL - 1] + sc->ap5soc[NL - 1];
+    rhsn[NL - 1] = (entfac / P.hoc[NL - 1]) * sc->eninoc[NL - 2] + sc->ajinoc[NL - 1] - sc->ap5noc[NL - 1];
+  } else {
   // ocisubs.F:176-193
   rhss[0] = (entfac / P.hoc[0]) * sc->enisoc[0] + (fnot / P.hoc[0]) * sc->txisoc + sc->ajisoc[0] - sc->ap3soc[0] + sc->ap5soc[0];
   rhsn[0] = (entfac / P.hoc[0]) * sc->eninoc[0] - (fnot / P.hoc[0]) * sc->txinoc + sc->ajinoc[0] + sc->ap3noc[0] - sc->ap5noc[0];
@@ -172,6 +185,7 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
                  (fnot / P.hoc[NL - 1]) * sc->bdrins;
   rhsn[NL - 1] = -(entfac / P.hoc[NL - 1]) * sc->eninoc[NL - 2] + sc->ajinoc[NL - 1] + sc->ap3noc[NL - 1] - sc->ap5noc[NL - 1] -
                  (fnot / P.hoc[NL - 1]) * sc->bdrinn;
+  }
   // ocisubs.F:199-206
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
 #pragma unroll
   for (int k = 0; k < NL - 1; ++k) {
     sc->dpiocp[k] = sc->dpioc[k];
-    sc->dpioc[k] = aiplay[k + 1] - aiplay[k];
+    sc->dpioc[k] = P.g.atm ? aiplay[k] - aiplay[k + 1] /* dpiat, src/atisubs.F:256 */ : aiplay[k + 1] - aiplay[k];
   }
 }
 
@@ -265,8 +279,10 @@ __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, cons
       if (k == 0) ap = B.f0A[0] * pl[0] + B.f0A[NL] * pl[1];
       else if (k == NL - 1) ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k];
       else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
+      if (P.g.atm && k == NL - 1 && gj == 1) // southern value of the top layer: src/vorsubs.F:470 reads row 2
+        ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pin[k];
       double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
-      if (k == NL - 1) q = q + B.ddynoc[o];
+      if (k == (P.g.atm ? 0 : NL - 1)) q = q + B.ddynoc[o]; // topography: ocean bottom layer nlo, atmosphere layer 1
       B.qo[P.g.fstride * k + o] = q;
     }
   }

@@ -257,8 +257,10 @@ __global__ __launch_bounds__(256) void k_ocqbdy(const QgBdyParams P) {
   if (k == 0) ap = P.f0A[0 + nl * 0] * pb + P.f0A[0 + nl * 1] * po[fs * 1 + ob];
   else if (k == nl - 1) ap = P.f0A[k + nl * (k - 1)] * po[fs * (k - 1) + ob] + P.f0A[k + nl * k] * pb;
   else ap = P.f0A[k + nl * (k - 1)] * po[fs * (k - 1) + ob] + P.f0A[k + nl * k] * pb + P.f0A[k + nl * (k + 1)] * po[fs * (k + 1) + ob];
+  if (P.g.atm && k == nl - 1 && side == 0) // atqzbd, southern value of the top layer: src/vorsubs.F:470 reads row 2
+    ap = P.f0A[k + nl * (k - 1)] * po[fs * (k - 1) + ob] + P.f0A[k + nl * k] * po[fs * k + oi];
   double q = P.bcfaco_f0 * (po[fs * k + oi] - pb) - ap + P.beta * P.yporel[gj - 1];
-  if (k == nl - 1) q = q + P.ddynoc[ob];
+  if (k == (P.g.atm ? 0 : nl - 1)) q = q + P.ddynoc[ob]; // topography: ocean layer nlo, atmosphere layer 1
   P.qo[fs * k + ob] = q;
 }
 

@@ -88,9 +88,16 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
   double qdot[NL];
 #pragma unroll
   for (int k = 0; k < NL; ++k) qdot[k] = dq[k];
-  qdot[0] = dq[0] + P.fohfac[0] * (wek - ent);
-  qdot[1] = dq[1] + P.fohfac[1] * ent;
-  qdot[NL - 1] = qdot[NL - 1] - P.bdrfac * d2bot;
+  if (CYC && P.g.atm) {
+    // atmosphere (src/qgasubs.F:128-131): entrainment and Ekman pumping act on the bottom layer 1 with the
+    // opposite sign, there is no drag term
+    qdot[0] = dq[0] + P.fohfac[0] * (ent - wek);
+    qdot[1] = dq[1] - P.fohfac[1] * ent;
+  } else {
+    qdot[0] = dq[0] + P.fohfac[0] * (wek - ent);
+    qdot[1] = dq[1] + P.fohfac[1] * ent;
+    qdot[NL - 1] = qdot[NL - 1] - P.bdrfac * d2bot;
+  }
   double ql[NL];
   double betay = P.beta * P.yporel[gj - 1];
 #pragma unroll
@@ -99,7 +106,8 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
     P.qnew[fs * k + o] = qn;
     ql[k] = qn - betay;
   }
-  ql[NL - 1] = ql[NL - 1] - ddy;
+  if (CYC && P.g.atm) ql[0] = ql[0] - ddy; // topography under layer 1, src/atisubs.F:117
+  else ql[NL - 1] = ql[NL - 1] - ddy;
   int c = CYC ? gi - 1 : gi - 2;
   if (c >= 0 && c < P.g.nk) {
 #pragma unroll

@@ -50,6 +50,7 @@ struct QgGeom {
   // y-slab view: global row = local row + joff; this handle owns local rows jlo..jhi;
   // jr0..jr1 = owned rows that are interior to the global domain (2..nyg-1).
   int nyg, joff, jlo, jhi, jr0, jr1;
+  int atm; // 1: atmospheric channel (qgcm_hip_params.atmos): cyclic kernels with the atmosphere's conventions
 };
 
 struct QgTendParams {

@@ -45,9 +45,6 @@ struct qgcm_hip_ctx {
   QgGeom g;
   int device;
   hipStream_t stream;
-  hipStream_t mstream[QG_MAXL]; // one side stream per mode: the three Helmholtz chains run concurrently
-  hipEvent_t ev_fork, ev_join[QG_MAXL];
-  bool mode_streams;            // QGCM_HIP_MODE_STREAMS=1 enables (measured slower: 140 vs 116 us/step at 5 km)
   double *p[2], *q[2];
   int ip, iq; // p[ip] = po, p[ip^1] = pom ; q[iq] = qo, q[iq^1] = qom
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
@@ -82,7 +79,8 @@ struct qgcm_hip_ctx {
   double kms[KN_COUNT];
   int klaunch[KN_COUNT];
   // graphs keyed by (ip, iq, phase)
-  std::map<int, hipGraphExec_t> graphs;
+  std::map<long long, hipGraphExec_t> graphs;
+  int avg_period = 25; // time levels are averaged after steps s with (s-1) mod avg_period == 0: ocean 25, atmosphere 100
   // ocean mixed layer (qgcm_hip_oml_init): three rotating sst buffers (is = sst, ism = sstm, spare = 3-is-ism)
   struct {
     bool on = false;
@@ -101,12 +99,23 @@ struct qgcm_hip_ctx {
   size_t dst_lds;
 };
 
-static const int kGraphBlock = 50;
+static const int kGraphBlock = 50; // y-slab step graphs (qgcm_hip_slab_steps)
 
 extern "C" const char *qgcm_hip_last_error(void) { return g_err; }
 extern "C" int qgcm_hip_abi_version(void) { return QGCM_HIP_ABI_VERSION; }
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Captured step graphs hold kernel parameters by value and raw device pointers: every call that changes
+// either (tables, homogeneous solutions, mixed-layer parameters, slab constants) drops them.
+static void drop_graphs(qgcm_hip_ctx *c) {
+  if (c->graphs.empty() && c->slab_graphs.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+  for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second);
+  c->graphs.clear();
+  c->slab_graphs.clear();
+}
 
 static int factorize(int n, int *fac) {
   int nf = 0;
@@ -160,6 +169,13 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   HIPCHECK(hipGetDevice(&c->device));
   QgGeom &g = c->g;
   g.nx = prm->nxpo; g.nl = prm->nlo; g.cyc = prm->cyclic;
+  g.atm = prm->atmos ? 1 : 0;
+  if (g.atm && !g.cyc) QG_FAIL("qgcm_hip_create: the atmosphere is a zonally periodic channel (atmos = 1 needs cyclic = 1)");
+  if (g.atm) {
+    c->avg_period = 100;   // src/q-gcm.F:1370
+    c->prm.delek = 0.0;    // no drag layer and no Del-4th term in qgastep / atadif
+    for (int k = 0; k < QG_MAXL; ++k) c->prm.ah2oc[k] = 0.0;
+  }
   g.nyg = prm->nypo;
   {
     // y-slab view: owned global rows g0..g1 (+ 3 halo rows towards each neighbour)
@@ -183,15 +199,6 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   g.fstride = (long)g.ldx * g.ny;
   g.wstride = (long)g.ldw * g.ny;
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int m = 0; m < g.nl; ++m) {
-    HIPCHECK(hipStreamCreateWithFlags(&c->mstream[m], hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&c->ev_join[m], hipEventDisableTiming));
-  }
-  HIPCHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  {
-    const char *e = getenv("QGCM_HIP_MODE_STREAMS");
-    c->mode_streams = (e && e[0] == '1');
-  }
   const size_t F = (size_t)g.fstride, W = (size_t)g.wstride;
   for (int i = 0; i < 2; ++i) {
     if (dalloc(&c->p[i], F * g.nl)) return 1;
@@ -265,11 +272,6 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->evpool) hipEventDestroy(e);
-  for (int m = 0; m < c->g.nl; ++m) {
-    hipStreamDestroy(c->mstream[m]);
-    hipEventDestroy(c->ev_join[m]);
-  }
-  hipEventDestroy(c->ev_fork);
   hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -315,6 +317,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
 extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const double *bd2oc, const double *ddynoc) {
   if (!c || !yporel || !bd2oc) QG_FAIL("qgcm_hip_set_grid: null argument");
   const QgGeom &g = c->g;
+  drop_graphs(c);
   HIPCHECK(hipMemcpy(c->yporel, yporel, sizeof(double) * g.ny, hipMemcpyHostToDevice));
   if (ddynoc) {
     if (upload2d(c, c->ddynoc, g.ldx, ddynoc, g.nx, g.ny)) return 1;
@@ -417,6 +420,7 @@ static int lu_factor(int n, double *a, int *piv) {
 extern "C" int qgcm_hip_set_homog_box(qgcm_hip_handle c, const double *ochom, const double *cdiffo, const double *cdhoc) {
   if (!c || !ochom || !cdiffo || !cdhoc) QG_FAIL("qgcm_hip_set_homog_box: null argument");
   if (c->g.cyc) QG_FAIL("qgcm_hip_set_homog_box: handle is cyclic");
+  drop_graphs(c);
   const QgGeom &g = c->g;
   const int nl = g.nl, n1 = nl - 1;
   if (upload2d(c, c->ochom, g.ldx, ochom, g.nx, (long)g.ny * n1)) return 1;
@@ -435,6 +439,7 @@ extern "C" int qgcm_hip_set_homog_cyc(qgcm_hip_handle c, const double *pch1oc, c
   if (!c || !pch1oc || !pch2oc || !pbhoc || !aipcho || !hc1soc || !hc2soc || !hc1noc || !hc2noc)
     QG_FAIL("qgcm_hip_set_homog_cyc: null argument");
   if (!c->g.cyc) QG_FAIL("qgcm_hip_set_homog_cyc: handle is a box ocean");
+  drop_graphs(c);
   const QgGeom &g = c->g;
   const int n1 = g.nl - 1;
   HIPCHECK(hipMemcpy(c->pch1, pch1oc, sizeof(double) * g.ny * n1, hipMemcpyHostToDevice));
@@ -961,32 +966,16 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
   if (check_ready(c, "qgcm_hip_ocinvq")) return 1;
   if (!c->whole) QG_FAIL("qgcm_hip_ocinvq: this handle is a y-slab; drive it with the slab building blocks");
   if (!c->homog_set) QG_FAIL("qgcm_hip_ocinvq: homogeneous solutions not set");
-  if (c->mode_streams && !c->profiling) {
-    // The nl modal Helmholtz problems are independent: run their
-    // transform -> Thomas -> transform chains on side streams so that the memory phase of
-    // one mode overlaps the arithmetic of another (each kernel alone is one lock-step
-    // round of waves).  Fork/join with events, which also captures into the HIP graph.
-    HIPCHECK(hipEventRecord(c->ev_fork, c->stream));
-    for (int m = 0; m < c->g.nl; ++m) {
-      hipStream_t st = c->mstream[m];
-      HIPCHECK(hipStreamWaitEvent(st, c->ev_fork, 0));
-      if (launch_dst(c, c->wrk, 1, false, m, st)) return 1;
-      if (launch_thomas(c, c->wrk, c->boc, c->betc, 1, 0, nullptr, nullptr, 0, 1, m, st)) return 1;
-      if (launch_dst(c, c->wrk, 1, true, m, st)) return 1;
-      HIPCHECK(hipEventRecord(c->ev_join[m], st));
-      HIPCHECK(hipStreamWaitEvent(c->stream, c->ev_join[m], 0));
-    }
-  } else {
-    if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
-    if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
-    if (!c->g.cyc && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
-    if (can_fuse_dst_unpack(c)) {
-      if (launch_dst_unpack(c, fuse_bdy)) return 1;
-      c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
-      return 0;
-    }
-    if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
+  // (A per-mode side-stream variant of this chain was measured slower - 140 vs 116 us/step at 5 km - and removed.)
+  if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
+  if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  if (!c->g.cyc && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
+  if (can_fuse_dst_unpack(c)) {
+    if (launch_dst_unpack(c, fuse_bdy)) return 1;
+    c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
+    return 0;
   }
+  if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
   if (c->g.cyc && launch_constr(c)) return 1; // cyclic: line and area sums of the transformed rows
   if (launch_unpack(c, fuse_bdy)) return 1;
   c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
@@ -1023,6 +1012,7 @@ extern "C" int qgcm_hip_oml_init(qgcm_hip_handle c, const qgcm_hip_oml_params *p
   const int nxt = g.nxt, nyt = g.ny - 1;
   if (nxt < 3 || nyt < 3) QG_FAIL("qgcm_hip_oml_init: grid too small");
   auto &o = c->oml;
+  drop_graphs(c);
   o.prm = *p;
   if (!o.sst[0]) {
     o.ldt = round_up(nxt, 16);
@@ -1217,7 +1207,7 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   if (c->oml.on && launch_oml(c)) return 1; // src/q-gcm.F:1232
   if (qgcm_hip_qgostep(c)) return 1;
   if (ocinvq_impl(c, true)) return 1; // ocqbdy fused into the unpack kernel
-  if ((s - 1) % 25 == 0) {
+  if ((s - 1) % c->avg_period == 0) {
     if (qgcm_hip_lf_average(c)) return 1; // incl. sst when the mixed layer is on
   }
   if (c->profiling) {
@@ -1238,10 +1228,16 @@ static void oml_rotate(qgcm_hip_ctx *c, int nsteps) {
   }
 }
 
-static int get_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
-  const int phase = (s0 - 1) % 25;
+// One captured block of B consecutive steps. B is even, so both buffer rotations are back where they started
+// after the block; the key carries everything else a captured step depends on: the position in the averaging
+// cycle and the sst rotation. 50-step blocks serve long runs (one graph for the ocean: 50 = 2 x 25), 10-step
+// blocks the tail and short runs (at most five graphs), the remainder is launched eagerly.
+static const int kGraphBlocks[2] = {50, 10};
+
+static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
+  const int phase = (s0 - 1) % c->avg_period;
   const int omk = c->oml.on ? 1 + 3 * c->oml.is + c->oml.ism : 0; // mixed layer on/off and its buffer rotation
-  const int key = (omk << 24) | (c->ip << 16) | (c->iq << 8) | phase;
+  const long long key = ((long long)B << 32) | (omk << 24) | (c->ip << 16) | (c->iq << 8) | phase;
   auto it = c->graphs.find(key);
   if (it != c->graphs.end()) {
     *out = it->second;
@@ -1251,7 +1247,7 @@ static int get_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   const int ip0 = c->ip, iq0 = c->iq, is0 = c->oml.is, ism0 = c->oml.ism;
   HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  for (int s = s0; s < s0 + kGraphBlock && !rc; ++s) rc = one_step(c, s);
+  for (int s = s0; s < s0 + B && !rc; ++s) rc = one_step(c, s);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
   c->ip = ip0; // capture does not execute: restore the rotation state
   c->iq = iq0;
@@ -1267,21 +1263,98 @@ static int get_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   return 0;
 }
 
+// dry = true only instantiates the graphs the run will replay (so that a timed region does not pay for it)
+static int steps_impl(qgcm_hip_ctx *c, int s0, int n, bool dry) {
+  int s = s0;
+  const int is0 = c->oml.is, ism0 = c->oml.ism;
+  for (int b = 0; b < 2 && !c->profiling; ++b) {
+    const int B = kGraphBlocks[b];
+    while (n >= B) {
+      hipGraphExec_t ge;
+      if (get_graph(c, s, B, &ge)) return 1;
+      if (!dry) HIPCHECK(hipGraphLaunch(ge, c->stream));
+      s += B;
+      n -= B;
+      if (c->oml.on) oml_rotate(c, B); // the p and q rotations are back where they started, sst has moved on
+    }
+  }
+  if (dry) {
+    c->oml.is = is0;
+    c->oml.ism = ism0;
+    return 0;
+  }
+  for (; n > 0; --n, ++s)
+    if (one_step(c, s)) return 1;
+  return 0;
+}
+
 extern "C" int qgcm_hip_steps(qgcm_hip_handle c, int s0, int n) {
   if (check_ready(c, "qgcm_hip_steps")) return 1;
   if (!c->whole) QG_FAIL("qgcm_hip_steps: this handle is a y-slab; drive it with the slab building blocks");
   if (s0 < 1 || n < 0) QG_FAIL("qgcm_hip_steps: bad step range");
-  int s = s0;
-  while (n >= kGraphBlock && !c->profiling) {
-    hipGraphExec_t ge;
-    if (get_graph(c, s, &ge)) return 1;
-    HIPCHECK(hipGraphLaunch(ge, c->stream));
-    s += kGraphBlock; // 50 steps: the p and q rotations are back where they started, sst has moved on
-    n -= kGraphBlock;
-    if (c->oml.on) oml_rotate(c, kGraphBlock);
+  return steps_impl(c, s0, n, false);
+}
+
+// ---------------------------------------------------------------------------
+// atmosphere: the same kernels under the reference's names
+// ---------------------------------------------------------------------------
+static int check_atm(qgcm_hip_ctx *c, const char *who) {
+  if (check_ready(c, who)) return 1;
+  if (!c->g.atm) QG_FAIL("%s: the handle was not created with qgcm_hip_params.atmos = 1", who);
+  return 0;
+}
+
+extern "C" int qgcm_hip_qgastep(qgcm_hip_handle c) {
+  if (check_atm(c, "qgcm_hip_qgastep")) return 1;
+  return qgcm_hip_qgostep(c);
+}
+
+extern "C" int qgcm_hip_atinvq(qgcm_hip_handle c) {
+  if (check_atm(c, "qgcm_hip_atinvq")) return 1;
+  return ocinvq_impl(c, false);
+}
+
+extern "C" int qgcm_hip_atqzbd(qgcm_hip_handle c) {
+  if (check_atm(c, "qgcm_hip_atqzbd")) return 1;
+  return launch_ocqbdy(c);
+}
+
+extern "C" int qgcm_hip_get_bsums(qgcm_hip_handle c, double *b) {
+  if (check_ready(c, "qgcm_hip_get_bsums")) return 1;
+  if (!b) QG_FAIL("qgcm_hip_get_bsums: null argument");
+  if (!c->g.cyc) QG_FAIL("qgcm_hip_get_bsums: only the zonally cyclic ocean and the atmosphere have boundary line sums");
+  QgScalars h;
+  HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  const int nl = c->g.nl;
+  for (int k = 0; k < nl; ++k) {
+    b[k] = h.ajisoc[k];
+    b[nl + k] = h.ajinoc[k];
+    b[2 * nl + k] = h.ap5soc[k];
+    b[3 * nl + k] = h.ap5noc[k];
   }
-  for (; n > 0; --n, ++s)
-    if (one_step(c, s)) return 1;
+  return 0;
+}
+
+// Coupled run with the forcing held between calls: the main loop of src/q-gcm.F:1220-1268 without xforc / oml / aml.
+// The ocean steps of the window are queued on the ocean handle's stream and the atmospheric steps on the
+// atmosphere's: with the forcing frozen the two halves do not exchange data inside the window, so the streams need
+// no cross dependencies and the GPU overlaps the atmosphere's small kernels with the ocean's.
+extern "C" int qgcm_hip_coupled_steps(qgcm_hip_handle oc, qgcm_hip_handle atm, int nt0, int n, int nstr) {
+  if (nt0 < 1 || n < 0 || nstr < 1) QG_FAIL("qgcm_hip_coupled_steps: bad step range");
+  if (oc && check_ready(oc, "qgcm_hip_coupled_steps")) return 1;
+  if (atm && check_atm(atm, "qgcm_hip_coupled_steps")) return 1;
+  if (oc && (oc->g.atm || !oc->whole)) QG_FAIL("qgcm_hip_coupled_steps: first handle must be a whole-domain ocean");
+  if (oc && n > 0) {
+    // ocean steps s with nt = 1 + (s-1)*nstr in [nt0, nt0+n-1]   (mod(nt,nstr) == 1, src/q-gcm.F:1222; nstr = 1 never
+    // steps the ocean in the reference - SURVEY 8d caveat - and neither does this)
+    if (nstr > 1) {
+      const int sfirst = (nt0 - 1 + nstr - 1) / nstr + 1; // smallest s with 1+(s-1)*nstr >= nt0
+      const int slast = (nt0 + n - 2) / nstr + 1;         // largest s with 1+(s-1)*nstr <= nt0+n-1
+      if (slast >= sfirst && steps_impl(oc, sfirst, slast - sfirst + 1, false)) return 1;
+    }
+  }
+  if (atm && n > 0 && steps_impl(atm, nt0, n, false)) return 1;
   return 0;
 }
 
@@ -1362,6 +1435,7 @@ extern "C" int qgcm_hip_set_thomas_consts(qgcm_hip_handle c, const double *gath_
   if (check_ready(c, "qgcm_hip_set_thomas_consts")) return 1;
   if (!gath_dev || nranks < 1 || nranks > 64) QG_FAIL("qgcm_hip_set_thomas_consts: bad argument");
   const size_t n = (size_t)TH_CST * c->g.nl * c->g.ldw * nranks;
+  drop_graphs(c);
   if (c->th_cgath_ranks != nranks) {
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (c->th_cgath) hipFree(c->th_cgath);
@@ -1514,10 +1588,7 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
 extern "C" int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle c, int on) {
   if (!c || !c->sc_comm) QG_FAIL("qgcm_hip_comm_set_halo_p2p: no communicator (qgcm_hip_comm_init)");
   HIPCHECK(hipStreamSynchronize(c->stream));
-  if (c->sc_comm->halo_p2p != (on != 0)) {
-    for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second); // captured steps contain the old exchange
-    c->slab_graphs.clear();
-  }
+  if (c->sc_comm->halo_p2p != (on != 0)) drop_graphs(c); // captured steps contain the old exchange
   c->sc_comm->halo_p2p = (on != 0);
   return 0;
 }
@@ -1659,11 +1730,8 @@ extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) 
   hipEvent_t a, b;
   HIPCHECK(hipEventCreate(&a));
   HIPCHECK(hipEventCreate(&b));
-  // instantiate any graph needed outside the timed region
-  if (n >= kGraphBlock) {
-    hipGraphExec_t ge;
-    if (get_graph(c, s0, &ge)) return 1;
-  }
+  // instantiate the graphs the run replays outside the timed region
+  if (steps_impl(c, s0, n, true)) return 1;
   HIPCHECK(hipEventRecord(a, c->stream));
   if (qgcm_hip_steps(c, s0, n)) return 1;
   HIPCHECK(hipEventRecord(b, c->stream));

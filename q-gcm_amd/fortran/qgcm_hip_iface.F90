@@ -22,6 +22,7 @@ module qgcm_hip_iface
     real(c_double) :: rdm2oc(QGCM_HIP_MAXL)
     real(c_double) :: aoc
     integer(c_int) :: slab_g0, slab_g1
+    integer(c_int) :: atmos   ! 1: the handle is the atmospheric channel (qgastep / atinvq / atqzbd)
   end type qgcm_hip_params
 
   ! struct qgcm_hip_oml_params: run-time parameters of the ocean mixed layer

@@ -49,6 +49,7 @@ contains
     p%fnot = fnot; p%beta = beta; p%dxo = dxo; p%dyo = dyo
     p%tdto = tdto; p%delek = delek; p%bccooc = bccooc; p%aoc = aoc
     p%slab_g0 = 0; p%slab_g1 = 0
+    p%atmos = 0
     p%ah2oc = 0.0d0; p%ah4oc = 0.0d0; p%hoc = 0.0d0; p%gpoc = 0.0d0
     p%amatoc = 0.0d0; p%ctl2moc = 0.0d0; p%ctm2loc = 0.0d0; p%rdm2oc = 0.0d0
     do k = 1, nlo

@@ -8,7 +8,7 @@ program performs before the time loop.  There is no CPU fallback: importing
 works anywhere, but constructing an :class:`OceanModel` without the built
 library or without a HIP device raises.
 """
-from .config import OceanConfig, OmlConfig, PRESETS, oml_preset, preset  # noqa: F401
-from .lib import QgcmHipError, load_library, library_path  # noqa: F401
-from .model import OceanModel  # noqa: F401
+from .config import AtmosConfig, OceanConfig, OmlConfig, PRESETS, atmos_of, atmos_preset, oml_preset, preset  # noqa: F401
+from .lib import QgcmHipError, check, load_library, library_path  # noqa: F401
+from .model import AtmosModel, OceanModel, coupled_steps  # noqa: F401
 from . import hostinit, synth  # noqa: F401

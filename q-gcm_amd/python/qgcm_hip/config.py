@@ -113,6 +113,65 @@ def oml_preset(cfg, sb_hflux=False, nb_hflux=False):
                      nb_hflux=nb_hflux, tnbdy=12.0 if nb_hflux else 0.0)
 
 
+@dataclass(frozen=True)
+class AtmosConfig:
+    """The atmospheric channel of a coupled run: MODULE parameters nxta, nyta, nla, fnot, beta
+    and the input.params entries dta, bccoat, ah4at, hat, gpat (src/in_param.f); dxa = ndxr*dxo (src/q-gcm.F:380).
+    The ocean-named properties let the start-up arithmetic of hostinit (shared with the cyclic ocean) read it."""
+    name: str
+    nxta: int
+    nyta: int
+    fnot: float
+    beta: float
+    dxa: float
+    nla: int = 3
+    dta: float = 180.0
+    bccoat: float = 1.0
+    ah4at: Tuple[float, ...] = (1.5e14, 1.5e14, 1.5e14)
+    hat: Tuple[float, ...] = (2000.0, 3000.0, 4000.0)
+    gpat: Tuple[float, ...] = (1.2, 0.4)
+    atmos = True
+    cyclic = True
+    delek = 0.0
+
+    nxpa = property(lambda self: self.nxta + 1)
+    nypa = property(lambda self: self.nyta + 1)
+    tdta = property(lambda self: 2.0 * self.dta)  # src/q-gcm.F:441
+    dya = property(lambda self: self.dxa)         # src/q-gcm.F:391
+    xla = property(lambda self: self.nxta * self.dxa)
+    yla = property(lambda self: self.nyta * self.dxa)
+    # the same quantities under the names the ocean code uses
+    nxto = property(lambda self: self.nxta)
+    nyto = property(lambda self: self.nyta)
+    nxpo = property(lambda self: self.nxta + 1)
+    nypo = property(lambda self: self.nyta + 1)
+    nlo = property(lambda self: self.nla)
+    dxo = property(lambda self: self.dxa)
+    dyo = property(lambda self: self.dxa)
+    dto = property(lambda self: self.dta)
+    tdto = property(lambda self: 2.0 * self.dta)
+    xlo = property(lambda self: self.nxta * self.dxa)
+    ylo = property(lambda self: self.nyta * self.dxa)
+    bccooc = property(lambda self: self.bccoat)
+    ah2oc = property(lambda self: (0.0,) * self.nla)
+    ah4oc = property(lambda self: self.ah4at)
+    hoc = property(lambda self: self.hat)
+    gpoc = property(lambda self: self.gpat)
+
+    def ypa(self):
+        """src/q-gcm.F:401-402"""
+        return np.arange(self.nypa, dtype=np.float64) * self.dya
+
+    def yporel(self):
+        """yparel, src/q-gcm.F:403"""
+        return self.ypa() - 0.5 * self.yla
+
+
+def atmos_of(cfg, **kw):
+    """The atmosphere that goes with an ocean configuration: same nxta, nyta, fnot, beta; dxa = ndxr*dxo."""
+    return AtmosConfig("atm_" + cfg.name, cfg.nxta, cfg.nyta, cfg.fnot, cfg.beta, cfg.ndxr * cfg.dxo, dta=cfg.dta, **kw)
+
+
 _NATL = dict(fnot=9.37456e-05, beta=1.75360e-11, cyclic=False)
 _SOCN = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True)
 
@@ -142,5 +201,20 @@ PRESETS = {
 }
 
 
+# coupled grids (oracle/ref_binding.CONFIGS "cpl_*"): the ocean half; atmos_preset gives the atmosphere.
+# cpl_natl5 = examples/double_gyre_coupled (BASELINE configs[3]): NAtl 5 km ocean under a 385 x 97 x 3 atmosphere.
+PRESETS["cpl_tiny"] = OceanConfig("cpl_tiny", 16, 12, 4, 3, 12, 3, dxo=1.0e4, dta=360.0, ah4oc=(3.2e10,) * 3, **_NATL)
+PRESETS["cpl_small"] = OceanConfig("cpl_small", 32, 20, 6, 5, 16, 3, dxo=5.0e3, **_NATL)
+PRESETS["cpl_natl5"] = OceanConfig("cpl_natl5", 384, 96, 60, 60, 16, 3, dxo=5.0e3, **_NATL)
+
+
 def preset(name):
     return PRESETS[name]
+
+
+def atmos_preset(name):
+    """Atmosphere of the coupled preset `name`; Del-6th coefficient scaled from the 80 km grid of
+    examples/double_gyre_coupled (ah4at = 1.5e14) to the grid spacing (same grid-scale damping rate per second)."""
+    oc = PRESETS[name]
+    r = oc.ndxr * oc.dxo / 8.0e4
+    return atmos_of(oc, ah4at=(1.5e14 * r ** 4,) * 3)

@@ -10,6 +10,12 @@ restated with numpy for the host side (init-only, not on the per-step path):
   ocqbdy   src/vorsubs.F:245-388     (boundary q; numpy twin used only at init)
   homsol   src/conhoms.F:376-641     (homogeneous solutions; the Helmholtz solves
                                       go through the HIP solver, see OceanModel)
+
+The atmospheric channel (cfg.atmos) shares all of it with the cyclic ocean; where the
+reference's atmosphere differs the functions branch on ``cfg.atmos``: eigmod without the Flierl normalisation
+(eigmode.f:309), topography under layer 1 (last argument of qcomp, src/q-gcm.F:738-749), atqzbd
+(src/vorsubs.F:396-480), dpiat = integral of pa(k)-pa(k+1) (src/conhoms.F:205-216), homsol on ypa
+(src/conhoms.F:644-810).
 """
 import numpy as np
 
@@ -17,8 +23,12 @@ PI = 3.14159265358979324
 TWOPI = 6.28318530717958648
 
 
-def eigmod(gpoc, hoc, fnot):
-    """Returns amatoc, rdm2oc, ctl2moc(k,m), ctm2loc(m,k) as Fortran-ordered arrays."""
+def eigmod(gpoc, hoc, fnot, atmos=False):
+    """Returns amatoc, rdm2oc, ctl2moc(k,m), ctm2loc(m,k) as Fortran-ordered arrays.
+    atmos: case 'Atmosphere' of the reference - no Flierl normalisation; the right eigenvectors keep the scaling
+    LAPACK's DTREVC gives them (largest component of magnitude 1).  Their sign comes out of LAPACK's Schur vectors and
+    is not restatable; positive at k = 1 matches the reference for the example parameters, and pa, qa depend on
+    neither scale nor sign of a mode."""
     h = np.asarray(hoc, dtype=np.float64)
     g = np.asarray(gpoc, dtype=np.float64)
     nl = len(h)
@@ -49,6 +59,8 @@ def eigmod(gpoc, hoc, fnot):
         fl = np.sqrt(htot / np.sum(h * R * R))  # Flierl normalisation, eigmode.f:310-328
         if R[0] < 0:
             fl = -fl
+        if atmos:
+            fl = (-1.0 if R[0] < 0 else 1.0) / np.abs(R).max()
         R = fl * R
         LR = np.sum(h * R * R)
         ctl2m[:, m] = h * R / LR   # ctl2m(k,m) = cl2m(m,k)
@@ -85,6 +97,11 @@ def xintp(v):
     return rows.sum() + 0.5 * (xxs + xxn)
 
 
+def _topo_layer(cfg):
+    """0-based layer that feels the topography: ocean nlo, atmosphere 1 (last argument of qcomp / merqcy)."""
+    return 0 if getattr(cfg, "atmos", False) else cfg.nlo - 1
+
+
 def _ap(A, p, k, fnot):
     nl = p.shape[2]
     if k == 0:
@@ -104,7 +121,7 @@ def qcomp(cfg, A, yporel, ddynoc, p):
         pk = p[:, :, k]
         lap = dx2fac * (pk[1:-1, :-2] + pk[:-2, 1:-1] + pk[2:, 1:-1] + pk[1:-1, 2:] - 4.0 * pk[1:-1, 1:-1]) + betay
         q[1:-1, 1:-1, k] = lap - cfg.fnot * _ap(A, p, k, cfg.fnot)[1:-1, 1:-1]
-    q[1:-1, 1:-1, nl - 1] += ddynoc[1:-1, 1:-1]
+    q[1:-1, 1:-1, _topo_layer(cfg)] += ddynoc[1:-1, 1:-1]
     return q
 
 
@@ -117,7 +134,7 @@ def merqcy(cfg, A, yporel, ddynoc, p, q):
         pk = p[:, :, k]
         lap = dx2fac * (pk[0, :-2] + pk[-2, 1:-1] + pk[1, 1:-1] + pk[0, 2:] - 4.0 * pk[0, 1:-1]) + betay
         q[0, 1:-1, k] = lap - cfg.fnot * _ap(A, p, k, cfg.fnot)[0, 1:-1]
-    q[0, 1:-1, nl - 1] += ddynoc[0, 1:-1]
+    q[0, 1:-1, _topo_layer(cfg)] += ddynoc[0, 1:-1]
     q[-1, 1:-1, :] = q[0, 1:-1, :]
 
 
@@ -127,12 +144,16 @@ def ocqbdy(cfg, A, yporel, ddynoc, p, q):
     dxom2 = 1.0 / (cfg.dxo * cfg.dxo)
     bcf = cfg.bccooc * dxom2 / (0.5 * cfg.bccooc + 1.0) / cfg.fnot
     F = cfg.fnot * np.asarray(A)  # f0Am/f0Ac/f0Ap are formed first, vorsubs.F:281-282
+    atm = getattr(cfg, "atmos", False)
     for k in range(nl):
         ap = _ap(F, p, k, cfg.fnot)
         pk = p[:, :, k]
-        q[:, 0, k] = bcf * (pk[:, 1] - pk[:, 0]) - ap[:, 0] + cfg.beta * yporel[0]
+        aps = ap[:, 0]
+        if atm and k == nl - 1:  # atqzbd, src/vorsubs.F:470: the southern value of the top layer reads row 2
+            aps = F[k, k - 1] * p[:, 0, k - 1] + F[k, k] * p[:, 1, k]
+        q[:, 0, k] = bcf * (pk[:, 1] - pk[:, 0]) - aps + cfg.beta * yporel[0]
         q[:, -1, k] = bcf * (pk[:, -2] - pk[:, -1]) - ap[:, -1] + cfg.beta * yporel[-1]
-        if k == nl - 1:
+        if k == _topo_layer(cfg):
             q[:, 0, k] += ddynoc[:, 0]
             q[:, -1, k] += ddynoc[:, -1]
         if not cfg.cyclic:
@@ -158,9 +179,10 @@ def constr(cfg, A, po, pom):
     nl = cfg.nlo
     s = np.zeros(2 * (nl - 1) + 4 * nl)
     dA = cfg.dxo * cfg.dyo
+    sgn = -1.0 if getattr(cfg, "atmos", False) else 1.0  # dpiat integrates pa(k) - pa(k+1), conhoms.F:205-216
     for k in range(nl - 1):
-        s[k] = xintp(po[:, :, k + 1] - po[:, :, k]) * dA
-        s[nl - 1 + k] = xintp(pom[:, :, k + 1] - pom[:, :, k]) * dA
+        s[k] = xintp(sgn * (po[:, :, k + 1] - po[:, :, k])) * dA
+        s[nl - 1 + k] = xintp(sgn * (pom[:, :, k + 1] - pom[:, :, k])) * dA
     if cfg.cyclic:
         o = 2 * (nl - 1)
 
@@ -210,8 +232,9 @@ def homsol_cyc(cfg, rdm2, bd2, yporel, helmholtz):
     for m in range(nl - 1):
         rd = rdm2[m + 1]
         boc = bd2 - rd
-        l1 = (yporel[-1] - yporel) / cfg.ylo
-        l2 = (yporel - yporel[0]) / cfg.ylo
+        yy = cfg.ypa() if getattr(cfg, "atmos", False) else yporel  # conhoms.F:664-665 uses ypa itself
+        l1 = (yy[-1] - yy) / cfg.ylo
+        l2 = (yy - yy[0]) / cfg.ylo
         w1 = helmholtz(np.asfortranarray(np.broadcast_to(l1, (nx, ny))), boc)
         w2 = helmholtz(np.asfortranarray(np.broadcast_to(l2, (nx, ny))), boc)
         f1 = l1[None, :] + rd * w1

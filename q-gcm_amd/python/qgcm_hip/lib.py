@@ -27,6 +27,7 @@ class Params(C.Structure):
         ("ctm2loc", C.c_double * (MAXL * MAXL)), ("rdm2oc", C.c_double * MAXL),
         ("aoc", C.c_double),
         ("slab_g0", C.c_int), ("slab_g1", C.c_int),
+        ("atmos", C.c_int),
     ]
 
 
@@ -47,6 +48,7 @@ SYMBOLS = [
     "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag",
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
+    "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps",
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
     "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
     "qgcm_hip_constr", "qgcm_hip_unpack",
@@ -87,6 +89,10 @@ def load_library():
     L.qgcm_hip_get_inv_diag.argtypes = [vp, dp, dp]
     for n in ("qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_sync"):
         getattr(L, n).argtypes = [vp]
+    for n in ("qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd"):
+        getattr(L, n).argtypes = [vp]
+    L.qgcm_hip_get_bsums.argtypes = [vp, dp]
+    L.qgcm_hip_coupled_steps.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.qgcm_hip_steps.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_helmholtz.argtypes = [vp, dp, dp]
     ip = C.POINTER(C.c_int)

@@ -43,14 +43,15 @@ class OceanModel:
             raise QgcmHipError("nlo=%d exceeds QGCM_HIP_MAXL" % nl)
         self.yporel = cfg.yporel()
         self.ddynoc = np.zeros((cfg.nxpo, cfg.nypo), order="F") if ddynoc is None else _f(ddynoc)
+        atmos = bool(getattr(cfg, "atmos", False))
         if consts is None:
-            A, rdm2, cl2m, cm2l = hostinit.eigmod(cfg.gpoc, cfg.hoc, cfg.fnot)
+            A, rdm2, cl2m, cm2l = hostinit.eigmod(cfg.gpoc, cfg.hoc, cfg.fnot, atmos=atmos)
         else:
             A, rdm2, cl2m, cm2l = (consts[k] for k in ("amatoc", "rdm2oc", "ctl2moc", "ctm2loc"))
         self.amatoc, self.rdm2oc, self.ctl2moc, self.ctm2loc = A, rdm2, cl2m, cm2l
         self.aoc, self.bd2oc = hostinit.bd2oc(cfg)
         p = Params()
-        p.nxpo, p.nypo, p.nlo, p.cyclic = cfg.nxpo, cfg.nypo, nl, int(cfg.cyclic)
+        p.nxpo, p.nypo, p.nlo, p.cyclic, p.atmos = cfg.nxpo, cfg.nypo, nl, int(cfg.cyclic), int(atmos)
         p.fnot, p.beta, p.dxo, p.dyo = cfg.fnot, cfg.beta, cfg.dxo, cfg.dyo
         p.tdto, p.delek, p.bccooc, p.aoc = cfg.tdto, cfg.delek, cfg.bccooc, self.aoc
         for k in range(nl):
@@ -258,3 +259,62 @@ class OceanModel:
         g = C.c_double()
         check(self.L.qgcm_hip_copy_bandwidth(self.h, C.c_size_t(nbytes), int(reps), C.byref(g)))
         return g.value
+
+
+_ATM_NAMES = {"amatat": "amatoc", "rdm2at": "rdm2oc", "ctl2mat": "ctl2moc", "ctm2lat": "ctm2loc",
+              "pch1at": "pch1oc", "pch2at": "pch2oc", "pbhat": "pbhoc", "aipcha": "aipcho", "hc1sat": "hc1soc",
+              "hc2sat": "hc2soc", "hc1nat": "hc1noc", "hc2nat": "hc2noc", "hbsiat": "hbsioc", "aipbha": "aipbho"}
+
+
+class AtmosModel(OceanModel):
+    """The atmospheric channel of a coupled run on the GPU.  The reference steps it with
+
+        call qgastep ; call atinvq ; call atqzbd (qa, pa)          (src/q-gcm.F:1262-1268)
+
+    on MODULE atstate / athomog arrays; the same three names are methods here.  ``cfg`` is an AtmosConfig; the
+    inherited accessors carry the atmosphere's arrays: get_state() = pa, pam, qa, qam; get_scalars() = dpiat,
+    dpiatp, atmcs, atmcn, atmcsp, atmcnp; steps(n) averages the time levels when mod(nt-1,100) == 0
+    (src/q-gcm.F:1370).  ``consts`` may carry the reference's own eigmod / homsol products under their atmosphere
+    names (amatat, ctl2mat, ..., pch1at, ...), as a drop-in host would pass them."""
+
+    def __init__(self, cfg, ddynat=None, device=-1, consts=None):
+        if consts is not None:
+            consts = {_ATM_NAMES.get(k, k): v for k, v in consts.items()}
+        OceanModel.__init__(self, cfg, ddynoc=ddynat, device=device, consts=consts)
+
+    def set_forcing(self, wekpa=None, entat=None, xan=None, txis=None, txin=None, enis=None, enin=None):
+        """wekpa, entat (p grid), xan(nla-1) and the line integrals txisat, txinat, enisat, eninat that
+        xforc / aml leave in MODULE atstate / athomog."""
+        OceanModel.set_forcing(self, wekpa, entat, xan)
+        if txis is not None or txin is not None or enis is not None or enin is not None:
+            self.set_cyc_forcing(0.0 if txis is None else txis, 0.0 if txin is None else txin, enis, enin)
+
+    def qgastep(self):
+        check(self.L.qgcm_hip_qgastep(self.h))
+
+    def atinvq(self):
+        check(self.L.qgcm_hip_atinvq(self.h))
+
+    def atqzbd(self):
+        check(self.L.qgcm_hip_atqzbd(self.h))
+
+    def get_bsums(self):
+        """ajisat, ajinat, ap5sat, ap5nat (nla each) of the last qgastep (valid after the following atinvq)."""
+        b = np.zeros(4 * self.cfg.nlo)
+        check(self.L.qgcm_hip_get_bsums(self.h, _dp(b)))
+        return b
+
+    pa = OceanModel.po
+    pam = OceanModel.pom
+    qa = OceanModel.qo
+    qam = OceanModel.qom
+
+
+def coupled_steps(ocean, atmos, nt0, n, nstr):
+    """n atmospheric steps nt = nt0.. with one ocean step before every one with mod(nt,nstr) == 1
+    (src/q-gcm.F:1220-1268), forcing held; either model may be None."""
+    L = (ocean or atmos).L
+    check(L.qgcm_hip_coupled_steps(ocean.h if ocean is not None else None, atmos.h if atmos is not None else None,
+                                   int(nt0), int(n), int(nstr)))
+    if atmos is not None:
+        atmos.step_index = int(nt0) + int(n)

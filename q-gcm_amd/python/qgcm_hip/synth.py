@@ -99,3 +99,38 @@ def mixed_layer_fields(cfg, oml, seed=None):
     yp = np.arange(cfg.nypo)[None, :] / (cfg.nypo - 1.0)
     ty = np.asfortranarray(2.0e-5 * np.sin(2.0 * np.pi * xp) * np.sin(np.pi * yp))
     return (np.asfortranarray(sst), np.asfortranarray(sstm), np.asfortranarray(fnet), np.asfortranarray(tx), ty)
+
+
+def atmos_fields(acfg, noise=1.0e-2, seed=385):
+    """Deterministic synthetic inputs of the atmospheric channel, all exactly periodic in x:
+    pa, pam (nxpa,nypa,nla): a zonal jet in thermal-wind balance with a wavenumber-2/4 planetary wave and smoothed
+    noise; wekpa, entat (p grid); ddynat (a smooth "mountain" under layer 1); xan and the line integrals txisat,
+    txinat, enisat, eninat that xforc / aml would supply.  Magnitudes follow a spun-up double_gyre_coupled run
+    (pa ~ 1e3 m^2 s^-2, wekpa ~ 1e-3 m s^-1)."""
+    nx, ny, nl = acfg.nxpa, acfg.nypa, acfg.nla
+    x = np.arange(nx)[:, None] / (nx - 1.0)
+    y = np.arange(ny)[None, :] / (ny - 1.0)
+    rng = np.random.default_rng(seed)
+    pa = np.zeros((nx, ny, nl), order="F")
+    for k in range(nl):
+        jet = -1500.0 * (1.0 + 0.5 * k) * np.tanh(4.0 * (y - 0.5))
+        wave = 400.0 * (1.0 + 0.3 * k) * np.sin(2 * np.pi * 2 * x + 0.7 * k) * np.sin(np.pi * y) ** 2 \
+            + 150.0 * np.cos(2 * np.pi * 4 * x - 0.4 * k) * np.sin(2 * np.pi * y)
+        r = rng.uniform(-1.0, 1.0, size=(nx - 1, ny))  # one period; 5-point smoothing, periodic in x
+        s = r.copy()
+        s[:, 1:-1] = 0.2 * (r[:, 1:-1] + np.roll(r, 1, axis=0)[:, 1:-1] + np.roll(r, -1, axis=0)[:, 1:-1]
+                            + r[:, :-2] + r[:, 2:])
+        s = np.vstack([s, s[:1]])
+        pa[:, :, k] = jet + wave + noise * 1500.0 * s
+    pa[-1, :, :] = pa[0, :, :]
+    pam = np.asfortranarray(0.985 * pa)
+    wekpa = np.asfortranarray(1.0e-3 * np.sin(2 * np.pi * x) * np.sin(np.pi * y) + 2.0e-4 * np.cos(2 * np.pi * 3 * x) * y)
+    entat = np.asfortranarray(3.0e-4 * np.cos(2 * np.pi * x) * np.sin(np.pi * y) ** 2)
+    ddynat = np.asfortranarray(2.0e-6 * np.exp(-((x - 0.3) ** 2 + (y - 0.45) ** 2) / 0.02) + 0.0 * y)
+    for a in (wekpa, entat, ddynat):
+        a[-1, :] = a[0, :]
+    area = acfg.xla * acfg.yla
+    return dict(pa=pa, pam=pam, wekpa=wekpa, entat=entat, ddynat=ddynat,
+                xan=np.array([2.0e-6 * area] + [0.0] * (nl - 2)), txis=3.0e2 * acfg.xla / 3.0e7,
+                txin=-2.0e2 * acfg.xla / 3.0e7, enis=np.array([1.0e-5 * acfg.xla] + [0.0] * (nl - 2)),
+                enin=np.array([-0.6e-5 * acfg.xla] + [0.0] * (nl - 2)))

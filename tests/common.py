@@ -91,3 +91,56 @@ def oml_load(model, g, cfg, is_oracle):
     else:
         model.oml_set_state(g["in_sst"], g["in_sstm"])
         model.oml_set_forcing(g["in_fnetoc"], g["in_wekto"], g["in_tauxo"], g["in_tauyo"])
+
+
+# ---- atmosphere fixtures (tests/golden/make_golden_atmos.py), SURVEY 8 row f3 ------------------------------
+ATM_CASES = (("atm_tiny", "cpl_tiny"), ("atm_small", "cpl_small"), ("atm_natl5", "cpl_natl5"))
+ATM_SNAPS = {"atm_tiny": (1, 2, 100, 101, 130), "atm_small": (1, 40), "atm_natl5": (1, 6, 101)}
+ATM_FIELDS = ("pa", "pam", "qa", "qam")
+
+
+def atm_inputs(g, acfg):
+    """Inputs of an atmosphere fixture. atm_natl5 stores every 4th row / column: the full fields are re-generated
+    from qgcm_hip.synth.atmos_fields and must reproduce the stored sample bit for bit."""
+    st = int(g["stride"]) if "stride" in g else 1
+    if st == 1:
+        return {k: g["in_" + k] for k in ("pa", "pam", "wekpa", "entat", "ddynat", "xan", "txis", "txin", "enis", "enin")}
+    from qgcm_hip import synth
+    f = synth.atmos_fields(acfg)
+    for k in ("pa", "pam", "wekpa", "entat", "ddynat"):
+        assert np.array_equal(f[k][::st, ::st], g["in_" + k]), "synthetic atmosphere input %s drifted from the fixture" % k
+    for k in ("xan", "txis", "txin", "enis", "enin"):
+        assert np.array_equal(np.asarray(f[k]), g["in_" + k]), k
+    return f
+
+
+def make_atm_oracle(acfg, g, f):
+    return ob.AtmosOracle(acfg.nxpa, acfg.nypa, acfg.nla, acfg.fnot, acfg.beta, acfg.dxa, acfg.dta, acfg.bccoat,
+                          acfg.ah4at, acfg.hat, acfg.gpat, g["c_yparel"], f["ddynat"])
+
+
+def atm_apply(model, f):
+    """Start-up sequence + forcing into an AtmosOracle or an AtmosModel (same method names)."""
+    model.set_p(f["pa"], f["pam"])
+    model.set_forcing(f["wekpa"], f["entat"], f["xan"], float(f["txis"]), float(f["txin"]), f["enis"], f["enin"])
+
+
+def atm_state_errs(model, g, tag):
+    st = int(g["stride"]) if "stride" in g else 1
+    s = model.get_state()
+    return {n: relerr(s[i][::st, ::st], g["%s_%s" % (tag, n)]) for i, n in enumerate(ATM_FIELDS)}
+
+
+def atm_load_snapshot(model, g, tag):
+    model.set_state(*[g["%s_%s" % (tag, n)] for n in ATM_FIELDS])
+    model.set_scalars(g[tag + "_scal"])
+
+
+def atm_scal_err(model, g, tag, acfg):
+    """dpiat relative to xla*yla*max|pa| (cancelling area integrals); atmc* relative to their maximum."""
+    s, r = model.get_scalars(), g[tag + "_scal"]
+    nl = acfg.nla
+    scale = acfg.xla * acfg.yla * np.abs(g[tag + "_pa"]).max()
+    e = np.abs(s[:2 * (nl - 1)] - r[:2 * (nl - 1)]).max() / scale
+    den = np.abs(r[2 * (nl - 1):]).max()
+    return float(max(e, np.abs(s[2 * (nl - 1):] - r[2 * (nl - 1):]).max() / den))

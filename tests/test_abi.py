@@ -27,13 +27,14 @@ def test_library_exports_all_symbols(repo_root):
     for s in header_symbols(repo_root):
         assert hasattr(L, s), s
     L.qgcm_hip_abi_version.restype = ctypes.c_int
-    assert L.qgcm_hip_abi_version() == 1
+    assert L.qgcm_hip_abi_version() == 2  # 2: qgcm_hip_params.atmos + the atmosphere entry points
 
 
 def test_params_struct_layout():
-    # 4 ints + 7 doubles + 4*MAXL + 3*MAXL^2 + MAXL + 1 doubles + 2 ints
+    # 4 ints + 7 doubles + 4*MAXL + 3*MAXL^2 + MAXL + 1 doubles + 3 ints (slab_g0, slab_g1, atmos) + 4 B tail padding
     n = lib.MAXL
-    assert ctypes.sizeof(lib.Params) == 4 * 4 + 8 * (7 + 4 * n + 3 * n * n + n + 1) + 2 * 4
+    assert ctypes.sizeof(lib.Params) == 4 * 4 + 8 * (7 + 4 * n + 3 * n * n + n + 1) + 3 * 4 + 4
+    assert lib.Params.atmos.offset == ctypes.sizeof(lib.Params) - 8
 
 
 def test_oml_params_struct_layout(repo_root):

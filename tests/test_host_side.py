@@ -87,3 +87,57 @@ def test_presets_match_reference_examples():
     yp = n5.yporel()
     assert yp[0] == -2.4e6 and yp[-1] == 2.4e6
     assert abs(n5.model_years_per_day(62.9) - 93.06) < 0.05
+
+
+# ---- atmosphere: the numpy start-up arithmetic of AtmosModel vs the coupled reference build ----
+@pytest.fixture(scope="module", params=["atm_tiny", "atm_small"])
+def atm_case(request):
+    from common import ATM_CASES
+    return config.atmos_preset(dict(ATM_CASES)[request.param]), load_golden(request.param)
+
+
+def test_atmos_eigmod_and_bd2at(atm_case):
+    acfg, g = atm_case
+    A, rd, cl, cm = hostinit.eigmod(acfg.gpat, acfg.hat, acfg.fnot, atmos=True)
+    assert np.array_equal(A, g["c_amatat"])
+    for got, key in ((rd, "c_rdm2at"), (cl, "c_ctl2mat"), (cm, "c_ctm2lat")):
+        assert relerr(got, g[key]) < 5e-15, key
+    aat, bd2 = hostinit.bd2oc(acfg)
+    assert aat == float(g["c_aat"]) and np.array_equal(bd2, g["c_bd2at"])
+    assert np.array_equal(acfg.yporel(), g["c_yparel"])
+
+
+def test_atmos_init_q_and_constraints(atm_case):
+    acfg, g = atm_case
+    yp = acfg.yporel()
+    qa = hostinit.q_from_p(acfg, g["c_amatat"], yp, g["in_ddynat"], g["in_pa"])
+    qam = hostinit.q_from_p(acfg, g["c_amatat"], yp, g["in_ddynat"], g["in_pam"])
+    assert relerr(qa, g["init_qa"]) < 1e-15 and relerr(qam, g["init_qam"]) < 1e-15
+    s = hostinit.constr(acfg, g["c_amatat"], g["in_pa"], g["in_pam"])
+    nl = acfg.nla
+    scale = acfg.xla * acfg.yla * np.abs(g["in_pa"]).max()
+    assert np.abs(s[:2 * (nl - 1)] - g["init_scal"][:2 * (nl - 1)]).max() < 1e-14 * scale
+    assert relerr(s[2 * (nl - 1):], g["init_scal"][2 * (nl - 1):]) < 1e-12
+
+
+def test_atmos_homsol_with_oracle_solver(atm_case):
+    from common import atm_inputs, make_atm_oracle
+    acfg, g = atm_case
+    o = make_atm_oracle(acfg, g, atm_inputs(g, acfg))
+    try:
+        h = hostinit.homsol_cyc(acfg, g["c_rdm2at"], g["c_bd2at"], g["c_yparel"], o.helmholtz)
+        big = max(np.abs(g["h_hc1sat"]).max(), np.abs(g["h_hc2nat"]).max())
+        for k, kk in (("pch1oc", "pch1at"), ("pch2oc", "pch2at"), ("pbhoc", "pbhat"), ("aipcho", "aipcha"),
+                      ("hbsioc", "hbsiat"), ("aipbho", "aipbha")):
+            assert relerr(h[k], g["h_" + kk]) < 1e-13, k
+        for k, kk in (("hc1soc", "hc1sat"), ("hc2soc", "hc2sat"), ("hc1noc", "hc1nat"), ("hc2noc", "hc2nat")):
+            assert np.abs(h[k] - g["h_" + kk]).max() / big < 1e-13, k
+    finally:
+        o.close()
+
+
+def test_coupled_presets_match_the_reference_example():
+    oc, at = config.preset("cpl_natl5"), config.atmos_preset("cpl_natl5")
+    assert (oc.nxpo, oc.nypo, oc.nstr) == (961, 961, 3)
+    assert (at.nxpa, at.nypa, at.nla, at.dxa, at.dta) == (385, 97, 3, 8.0e4, 180.0)
+    assert at.ah4at == (1.5e14,) * 3 and at.hat == (2000.0, 3000.0, 4000.0) and at.gpat == (1.2, 0.4)
