@@ -140,6 +140,39 @@ def cpu_baseline(cfg, po, wek, budget_s=15.0):
                       "%d OpenMP threads, %.1f s" % (n, WORKLOAD, cores, dt)}
 
 
+def coupled_figure(cfg, po, wek, device, nocean=400):
+    """double_gyre_coupled (BASELINE configs[3]): ocean steps/s of the coupled main loop (1 ocean + nstr atmospheric
+    steps per ocean step, src/q-gcm.F:1220-1268) and the atmosphere's own step time."""
+    import torch
+    from qgcm_hip import AtmosModel, OceanModel, atmos_of, coupled_steps, synth
+    at = atmos_of(cfg)
+    f = synth.atmos_fields(at)
+    a = AtmosModel(at, ddynat=f["ddynat"], device=device)
+    a.set_p(f["pa"], f["pam"])
+    a.set_forcing(f["wekpa"], f["entat"], f["xan"], f["txis"], f["txin"], f["enis"], f["enin"])
+    o = OceanModel(cfg, device=device)
+    o.set_p(po, po)
+    o.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+    nstr = cfg.nstr
+    a.steps(200, s0=1)                      # atmosphere alone: graphs of both averaging phases instantiated
+    ms_a = a.time_steps(1200, s0=201)
+    nt = 1401
+    coupled_steps(o, a, nt, 100 * nstr, nstr)   # warm-up of the coupled loop (instantiates the ocean's graphs)
+    nt += 100 * nstr
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    coupled_steps(o, a, nt, nocean * nstr, nstr)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(np.isfinite(a.get_state()[0]).all() and np.isfinite(o.get_state()[0]).all())
+    a.close()
+    o.close()
+    return {"ocean_steps_per_s": round(nocean / dt, 2), "ms_per_ocean_step": round(1e3 * dt / nocean, 5),
+            "atmos_steps_per_ocean_step": nstr, "atmos_alone_us_per_step": round(1e3 * ms_a / 1200, 3),
+            "atmos_grid": [at.nxpa, at.nypa, at.nla], "model_years_per_day": round(cfg.model_years_per_day(nocean / dt), 1),
+            "state_finite": ok, "note": "forcing held; ocean and atmosphere on their own HIP streams of one GPU"}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary, if any."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -469,6 +502,15 @@ def main():
                                    "grid": [cfg_s.nxpo, cfg_s.nypo, cfg_s.nlo], "state_finite": ok_s}
         except Exception as e:  # noqa: BLE001 - secondary figure only
             out["socn5_cyclic"] = {"error": repr(e)}
+        # Secondary figure: BASELINE configs[3] double_gyre_coupled - the NAtl 5 km ocean under the 385 x 97 x 3
+        # atmosphere, three atmospheric steps (qgastep, atinvq, atqzbd) per ocean step, both on this
+        # GPU on their own streams, forcing held (xforc / aml / oml belong to the host side of a coupled run).
+        try:
+            if not secondary:
+                raise RuntimeError("skipped (QGCM_BENCH_NO_SECONDARY=1)")
+            out["coupled"] = coupled_figure(cfg, po, wek, local_rank)
+        except Exception as e:  # noqa: BLE001 - secondary figure only
+            out["coupled"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             model.close()
             out["cpu_baseline"] = cpu_baseline(cfg, po, wek)

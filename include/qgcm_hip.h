@@ -92,6 +92,10 @@ int qgcm_hip_abi_version(void);
  * ddynoc(nxpo,nypo).  Builds the device-side Thomas tables. */
 int qgcm_hip_set_grid(qgcm_hip_handle h, const double *yporel, const double *bd2oc,
                       const double *ddynoc);
+/* The part of set_grid that does not need bd2oc: yporel and ddynoc only.  The main program calls ocqbdy / atqzbd on
+ * host arrays (src/q-gcm.F:724-725, 743-744) before it computes bd2oc (:932-972); qgcm_hip_ocqbdy_host needs no more
+ * than this.  The stepping entry points still require qgcm_hip_set_grid. */
+int qgcm_hip_set_geometry(qgcm_hip_handle h, const double *yporel, const double *ddynoc);
 
 /* Products of homsol (src/conhoms.F:544-641 box / 376-543 cyclic).
  * box:    ochom(nxpo,nypo,nlo-1), cdiffo(nlo,nlo-1), cdhoc(nlo-1,nlo-1)
@@ -132,6 +136,11 @@ int qgcm_hip_qgostep(qgcm_hip_handle h);    /* replaces "call qgostep"        q-
 int qgcm_hip_ocinvq(qgcm_hip_handle h);     /* replaces "call ocinvq"         q-gcm.F:1246 */
 int qgcm_hip_ocqbdy(qgcm_hip_handle h);     /* replaces "call ocqbdy (qo,po)" q-gcm.F:1249 */
 int qgcm_hip_lf_average(qgcm_hip_handle h); /* ocean part of q-gcm.F:1328-1366 (incl. sst once qgcm_hip_oml_init was called) */
+/* "call ocqbdy (q, p)" / "call atqzbd (q, p)" on HOST arrays, as the main program does at start-up for both time
+ * levels before the device owns the state (src/q-gcm.F:724-725, 743-744): p(nxpo,nypo,nlo) is uploaded to scratch,
+ * the boundary PV kernel runs, and the boundary ring of q(nxpo,nypo,nlo) is written back (interior untouched).
+ * Does not touch the device-resident state. Synchronous. */
+int qgcm_hip_ocqbdy_host(qgcm_hip_handle h, double *q, const double *p);
 /* n whole ocean steps starting at 1-based ocean step index s0: qgostep, ocinvq,
  * ocqbdy and, when mod(s-1,25)==0, the averaging (nt = 1+(s-1)*nstr in
  * q-gcm.F:1222,1328).  Uses captured HIP graphs. */

@@ -64,6 +64,7 @@ struct qgcm_hip_ctx {
   int fftN, nfac, fac[QG_MAXFAC];
   QgConstr cs;
   bool grid_set, homog_set;
+  bool geom_set = false; // yporel / ddynoc are on the device (qgcm_hip_set_geometry or set_grid)
   bool whole; // the handle owns the whole domain (no y-slab neighbours)
   bool dst_single = false; // generic row kernels run single-buffer (in-place) stages
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
@@ -314,14 +315,22 @@ static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* 
 static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
                          const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st);
 
-extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const double *bd2oc, const double *ddynoc) {
-  if (!c || !yporel || !bd2oc) QG_FAIL("qgcm_hip_set_grid: null argument");
+extern "C" int qgcm_hip_set_geometry(qgcm_hip_handle c, const double *yporel, const double *ddynoc) {
+  if (!c || !yporel) QG_FAIL("qgcm_hip_set_geometry: null argument");
   const QgGeom &g = c->g;
   drop_graphs(c);
   HIPCHECK(hipMemcpy(c->yporel, yporel, sizeof(double) * g.ny, hipMemcpyHostToDevice));
   if (ddynoc) {
     if (upload2d(c, c->ddynoc, g.ldx, ddynoc, g.nx, g.ny)) return 1;
   }
+  c->geom_set = true;
+  return 0;
+}
+
+extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const double *bd2oc, const double *ddynoc) {
+  if (!c || !yporel || !bd2oc) QG_FAIL("qgcm_hip_set_grid: null argument");
+  const QgGeom &g = c->g;
+  if (qgcm_hip_set_geometry(c, yporel, ddynoc)) return 1;
   c->bd2oc.assign(bd2oc, bd2oc + g.nxt);
   // Thomas diagonal + chunk-entry pivots per mode: boc = bd2oc - rdm2oc(m)   (src/ocisubs.F:148-150)
   c->thR = thomas_rows_per_chunk(g.jr1 - g.jr0 + 1);
@@ -987,6 +996,34 @@ extern "C" int qgcm_hip_ocinvq(qgcm_hip_handle c) { return ocinvq_impl(c, false)
 extern "C" int qgcm_hip_ocqbdy(qgcm_hip_handle c) {
   if (check_ready(c, "qgcm_hip_ocqbdy")) return 1;
   return launch_ocqbdy(c);
+}
+
+// ocqbdy / atqzbd on host arrays (start-up calls of the main program, src/q-gcm.F:724-725, 743-744)
+extern "C" int qgcm_hip_ocqbdy_host(qgcm_hip_handle c, double *q, const double *p) {
+  if (!c) QG_FAIL("qgcm_hip_ocqbdy_host: null handle");
+  if (!c->geom_set) QG_FAIL("qgcm_hip_ocqbdy_host: neither qgcm_hip_set_geometry nor qgcm_hip_set_grid has been called");
+  if (!q || !p) QG_FAIL("qgcm_hip_ocqbdy_host: null argument");
+  if (!c->whole) QG_FAIL("qgcm_hip_ocqbdy_host: only for a handle that owns the whole domain");
+  const QgGeom &g = c->g;
+  const size_t n = (size_t)g.fstride * g.nl;
+  double *dp = nullptr, *dq = nullptr;
+  if (dalloc(&dp, n) || dalloc(&dq, n)) return 1;
+  const long rows = (long)g.ny * g.nl;
+  int rc = upload2d(c, dp, g.ldx, p, g.nx, rows) || upload2d(c, dq, g.ldx, q, g.nx, rows);
+  if (!rc) {
+    QgBdyParams P;
+    fill_bdy_params(c, P);
+    P.po = dp;
+    P.qo = dq;
+    const int nmax = g.nx > g.ny ? g.nx : g.ny;
+    hipLaunchKernelGGL(k_ocqbdy, dim3((nmax + 255) / 256, g.cyc ? 2 : 4, g.nl), dim3(256), 0, c->stream, P);
+    rc = hipGetLastError() != hipSuccess;
+    if (rc) snprintf(g_err, sizeof(g_err), "qgcm_hip_ocqbdy_host: launch failed");
+  }
+  if (!rc) rc = download2d(c, q, dq, g.ldx, g.nx, rows);
+  hipFree(dp);
+  hipFree(dq);
+  return rc;
 }
 
 static int launch_oml_average(qgcm_hip_ctx *c);

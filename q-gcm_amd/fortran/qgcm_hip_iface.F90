@@ -28,7 +28,7 @@ module qgcm_hip_iface
   ! struct qgcm_hip_oml_params: run-time parameters of the ocean mixed layer
   type, bind(C) :: qgcm_hip_oml_params
     real(c_double) :: hmoc, toc1, toc2, st2d, st4d, ycexp, rrcpoc, tsbdy, tnbdy
-    integer(c_int) :: sb_hflux, nb_hflux
+    integer(c_int) :: sb_flag, nb_flag   ! sb_hflux, nb_hflux of the C struct (those names are cpp macros in reference builds)
   end type qgcm_hip_oml_params
 
   interface
@@ -49,6 +49,11 @@ module qgcm_hip_iface
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
       real(c_double), intent(in) :: yporel(*), bd2oc(*), ddynoc(*)
+    end function
+    integer(c_int) function qgcm_hip_set_geometry(h, yporel, ddynoc) bind(C, name='qgcm_hip_set_geometry')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: yporel(*), ddynoc(*)
     end function
     integer(c_int) function qgcm_hip_set_homog_box(h, ochom, cdiffo, cdhoc) bind(C, name='qgcm_hip_set_homog_box')
       import :: c_ptr, c_int, c_double
@@ -104,6 +109,36 @@ module qgcm_hip_iface
     integer(c_int) function qgcm_hip_ocqbdy(h) bind(C, name='qgcm_hip_ocqbdy')
       import :: c_ptr, c_int
       type(c_ptr), value :: h
+    end function
+    ! "call ocqbdy (q, p)" / "call atqzbd (q, p)" on host arrays (start-up calls, src/q-gcm.F:724-725, 743-744)
+    integer(c_int) function qgcm_hip_ocqbdy_host(h, q, p) bind(C, name='qgcm_hip_ocqbdy_host')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(inout) :: q(*)
+      real(c_double), intent(in) :: p(*)
+    end function
+    ! atmosphere path (handles created with prm%atmos = 1): src/q-gcm.F:1262-1268
+    integer(c_int) function qgcm_hip_qgastep(h) bind(C, name='qgcm_hip_qgastep')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_atinvq(h) bind(C, name='qgcm_hip_atinvq')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_atqzbd(h) bind(C, name='qgcm_hip_atqzbd')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_get_bsums(h, b) bind(C, name='qgcm_hip_get_bsums')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: b(*)
+    end function
+    integer(c_int) function qgcm_hip_coupled_steps(oc, atm, nt0, n, nstr) bind(C, name='qgcm_hip_coupled_steps')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: oc, atm
+      integer(c_int), value :: nt0, n, nstr
     end function
     integer(c_int) function qgcm_hip_lf_average(h) bind(C, name='qgcm_hip_lf_average')
       import :: c_ptr, c_int

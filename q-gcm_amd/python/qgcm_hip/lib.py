@@ -43,10 +43,10 @@ class OmlParams(C.Structure):
 # every symbol include/qgcm_hip.h declares
 SYMBOLS = [
     "qgcm_hip_create", "qgcm_hip_destroy", "qgcm_hip_last_error", "qgcm_hip_abi_version",
-    "qgcm_hip_set_grid", "qgcm_hip_set_homog_box", "qgcm_hip_set_homog_cyc",
+    "qgcm_hip_set_grid", "qgcm_hip_set_geometry", "qgcm_hip_set_homog_box", "qgcm_hip_set_homog_cyc",
     "qgcm_hip_set_state", "qgcm_hip_get_state", "qgcm_hip_set_forcing", "qgcm_hip_set_cyc_forcing",
     "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag",
-    "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average",
+    "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_ocqbdy_host",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
     "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps",
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
@@ -78,6 +78,7 @@ def load_library():
     L.qgcm_hip_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
     L.qgcm_hip_destroy.argtypes = [vp]
     L.qgcm_hip_set_grid.argtypes = [vp, dp, dp, dp]
+    L.qgcm_hip_set_geometry.argtypes = [vp, dp, dp]
     L.qgcm_hip_set_homog_box.argtypes = [vp, dp, dp, dp]
     L.qgcm_hip_set_homog_cyc.argtypes = [vp] + [dp] * 8 + [C.c_double, C.c_double]
     L.qgcm_hip_set_state.argtypes = [vp, dp, dp, dp, dp]
@@ -93,6 +94,7 @@ def load_library():
         getattr(L, n).argtypes = [vp]
     L.qgcm_hip_get_bsums.argtypes = [vp, dp]
     L.qgcm_hip_coupled_steps.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.qgcm_hip_ocqbdy_host.argtypes = [vp, dp, dp]
     L.qgcm_hip_steps.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_helmholtz.argtypes = [vp, dp, dp]
     ip = C.POINTER(C.c_int)

@@ -169,6 +169,13 @@ class OceanModel:
     def lf_average(self):
         check(self.L.qgcm_hip_lf_average(self.h))
 
+    def ocqbdy_host(self, q, p):
+        """`call ocqbdy (q, p)` / `call atqzbd (q, p)` on host arrays (start-up use, src/q-gcm.F:724-725, 743-744):
+        returns q with its boundary ring recomputed from p; the device-resident state is not touched."""
+        q = np.array(q, dtype=np.float64, order="F", copy=True)
+        check(self.L.qgcm_hip_ocqbdy_host(self.h, _dp(q), _dp(_f(p))))
+        return q
+
     def steps(self, n, s0=None):
         """n whole ocean steps (q-gcm.F:1243-1249 + the averaging of :1328)."""
         s0 = self.step_index if s0 is None else int(s0)

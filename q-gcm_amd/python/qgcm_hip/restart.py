@@ -31,12 +31,14 @@ def _put(f, *arrays):
     f.write(struct.pack("<i", len(body)))
 
 
-def read_restart(path, cfg):
-    """-> dict(tyrs, po, pom, sst, sstm, ast, astm, hmixa, hmixam) of an ocean_only dump for grid `cfg`."""
+def read_restart(path, cfg, coupled=False):
+    """-> dict(tyrs, po, pom, sst, sstm, ast, astm, hmixa, hmixam) of an ocean_only dump for grid `cfg`;
+    coupled=True: the dump of a coupled build, which also carries pa, pam (nxta+1, nyta+1, 3)."""
     np3, nT, nA = cfg.nxpo * cfg.nypo * cfg.nlo, cfg.nxto * cfg.nyto, cfg.nxta * cfg.nyta
     with open(path, "rb") as f:
         t = _rec(f)
         p = _rec(f)
+        pa = _rec(f) if coupled else None
         s = _rec(f)
         a = _rec(f)
         h = _rec(f)
@@ -44,8 +46,15 @@ def read_restart(path, cfg):
         raise ValueError("restart file %s does not match grid %s" % (path, cfg.name))
     sh3, shT, shA = (cfg.nxpo, cfg.nypo, cfg.nlo), (cfg.nxto, cfg.nyto), (cfg.nxta, cfg.nyta)
     r = lambda v, sh: np.asfortranarray(v.reshape(sh, order="F"))
-    return dict(tyrs=float(t[0]), po=r(p[:np3], sh3), pom=r(p[np3:], sh3), sst=r(s[:nT], shT), sstm=r(s[nT:], shT),
-                ast=r(a[:nA], shA), astm=r(a[nA:], shA), hmixa=r(h[:nA], shA), hmixam=r(h[nA:], shA))
+    out = dict(tyrs=float(t[0]), po=r(p[:np3], sh3), pom=r(p[np3:], sh3), sst=r(s[:nT], shT), sstm=r(s[nT:], shT),
+               ast=r(a[:nA], shA), astm=r(a[nA:], shA), hmixa=r(h[:nA], shA), hmixam=r(h[nA:], shA))
+    if coupled:
+        sha = (cfg.nxta + 1, cfg.nyta + 1, 3)
+        na3 = sha[0] * sha[1] * sha[2]
+        if pa.size != 2 * na3:
+            raise ValueError("restart file %s: atmospheric record does not match grid %s" % (path, cfg.name))
+        out.update(pa=r(pa[:na3], sha), pam=r(pa[na3:], sha))
+    return out
 
 
 def write_restart(path, cfg, tyrs, po, pom, sst=None, sstm=None, ast=None, astm=None, hmixa=None, hmixam=None):

@@ -1,0 +1,39 @@
+"""Cases of the drop-in test (tests/test_dropin.py, tests/golden/make_golden_dropin.py): the reference main
+program src/q-gcm.F over the shim, one executable per compile-time grid."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+DROP = os.path.join(ROOT, "q-gcm_amd", "fortran", "dropin")
+NSTEPS = 120
+# (ocean steps, tolerance on max|difference| / max|reference| of every restart field).  The coupled model carries
+# switches (convective adjustment of both mixed layers, src/amlsubs.F / src/omlsubs.F) that amplify rounding: the
+# UNMODIFIED reference run with 1 vs 5 OpenMP threads (different summation order in xintp) differs by 1.8e-3 in po
+# after 30 ocean steps and 5e-4 after 120, while 2 vs 1 threads stay identical for 30 steps - hence one tight
+# single-step comparison and one loose long one for that case.
+RUNS = {"box_tiny": ((120, 1e-9),), "cyc_tiny": ((120, 1e-9),), "cpl_tiny": ((1, 1e-12), (120, 2e-2))}
+
+# cfg -> ((nxta, nyta, nxaooc, nyaooc, ndxr, nlo, fnot, beta), mode); dims as oracle/ref_binding.CONFIGS
+CASES = {
+    "box_tiny": ((8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11"), "box"),
+    "cyc_tiny": ((4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11"), "cyclic"),
+    "cpl_tiny": ((16, 12, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11"), "coupled"),
+}
+
+
+def exe_path(cfg, which):
+    return os.path.join(ROOT, "q-gcm_amd", "fortran", "_dropin", cfg, "q-gcm_" + which)
+
+
+def golden_name(cfg, nsteps):
+    return "dropin_%s_lastday%s.bin" % (cfg, "" if nsteps == NSTEPS else "_%d" % nsteps)
+
+
+def prepare_case(cfg, rundir, nsteps=NSTEPS):
+    subprocess.check_call([sys.executable, os.path.join(DROP, "make_case.py"), cfg, rundir, str(nsteps)],
+                          stdout=subprocess.DEVNULL)
+    if CASES[cfg][1] == "coupled":  # initial state of examples/double_gyre_coupled: radiative balance
+        p = os.path.join(rundir, "input.params")
+        txt = open(p).read().replace("\nzero\n", "\nrbal\n")
+        open(p, "w").write(txt)
