@@ -80,6 +80,17 @@ def host_cores():
     return min(n, 64)  # the reference parallelises over j only; more threads than that do not help it
 
 
+def cpu_model():
+    """`Model name` of lscpu (SURVEY 8d asks for it beside the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, po, wek, budget_s=15.0):
     """Reference (or port) ocean steps/s on the host cores; bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -134,7 +145,7 @@ def cpu_baseline(cfg, po, wek, budget_s=15.0):
         set_threads(cores)
     except Exception as e:  # noqa: BLE001
         print("cpu_baseline: single-thread timing skipped (%r)" % (e,), file=sys.stderr)
-    return {"value": round(sps, 3), "unit": "steps/s", "cores": cores, "kind": kind, "value_1_thread": one,
+    return {"value": round(sps, 3), "unit": "steps/s", "cores": cores, "kind": kind, "cpu_model": cpu_model(), "value_1_thread": one,
             "ms_per_step": round(1e3 / sps, 4), "model_years_per_day": round(cfg.model_years_per_day(sps), 2),
             "sample": "%d ocean steps of the same %s workload (Gaussian-eddy IC, double-gyre wind), "
                       "%d OpenMP threads, %.1f s" % (n, WORKLOAD, cores, dt)}
@@ -230,7 +241,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
         return float(t.item()), bool(fin.item() > 0.5)
 
-    def line(wall, finite, driver):
+    def line(wall, finite, driver, library_exchanges="ok"):
         basin_sps = args.steps / wall
         npts = cfg5.nxpo * cfg5.nypo
         return json.dumps({
@@ -248,6 +259,8 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             "basin_steps_per_s": round(basin_sps, 2),
             "model_years_per_day": round(cfg5.model_years_per_day(basin_sps), 1),
             "state_finite": finite,
+            "library_exchanges": library_exchanges,   # "ok" | "not tried" | "stalled" (watchdog) | "failed"
+            "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
             "step_hbm_frac_per_gpu": round(56 * npts * 8.0 * basin_sps / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": None, "cpu_baseline": None,
         }) + "\n"
@@ -257,6 +270,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     drv_torch = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
     wall_t, fin_t = measure()
     best = (wall_t, fin_t, drv_torch)
+    lib_status = "not tried"
     use_library = os.environ.get("QGCM_BENCH_EXCHANGES", "library") == "library" and dist.get_backend() == "nccl"
     if use_library:
         # 2. The exchanges issued by the library itself (qgcm_hip_slab_steps: RCCL from C++ on the same stream, the
@@ -266,11 +280,14 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         import threading
 
         def bail():
+            # The stall goes INTO the record (a SCALE file must not hide it) and the run fails: the value printed is
+            # the torch.distributed measurement taken before, the exit code is non-zero. Nothing is restarted.
             if rank == 0:
-                real_stdout.write(line(*best))
+                real_stdout.write(line(best[0], best[1], best[2] + "; LIBRARY-ISSUED EXCHANGES STALLED (watchdog fired)",
+                                       library_exchanges="stalled"))
                 real_stdout.flush()
-            print("bench.py: library-issued exchanges stalled; reported the torch.distributed measurement", file=sys.stderr)
-            os._exit(0)
+            print("bench.py: library-issued exchanges stalled; reported the torch.distributed measurement, exit 3", file=sys.stderr)
+            os._exit(3)
         dog = threading.Timer(float(os.environ.get("QGCM_BENCH_WATCHDOG_S", "240")), bail)
         dog.daemon = True
         dog.start()
@@ -289,6 +306,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             ok = 0.0
         t = torch.tensor([ok], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        lib_status = "ok" if t.item() > 0.5 else "failed (see stderr); torch.distributed driver reported"
         if t.item() > 0.5:
             driver = "library-issued RCCL (qgcm_hip_slab_steps), verified bitwise against the torch.distributed driver"
 
@@ -331,7 +349,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         dog.cancel()
     dist.barrier()
     if rank == 0:
-        real_stdout.write(line(*best))
+        real_stdout.write(line(*best, library_exchanges=lib_status))
         real_stdout.flush()
     dist.destroy_process_group()
 
@@ -427,8 +445,12 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])
         tot_ms, nl = prof[dom]
         avg_us = 1e3 * tot_ms / max(nl, 1)
+        # `achieved` divides the bytes this kernel HAS to move (its compulsory traffic, "own": the time levels rotate
+        # instead of being copied, so k_tend moves 21 fields, not the 24 of SURVEY 8d's reference-algorithm count) by
+        # the launch time; rocprofv3 --pmc confirms that figure (`traffic`). The SURVEY count is kept as a labelled
+        # secondary: it credits bytes the kernel never touches and once exceeded the measured copy bandwidth.
         f_survey, f_own = ALGO_FIELDS[dom]
-        abytes = f_survey * npts * 8.0
+        abytes = f_own * npts * 8.0
         achieved = abytes / (avg_us * 1e-6) / 1e9
         copy_gbs = model.copy_bandwidth(1 << 30, 10)
         steps_per_s = world * args.steps / wall
@@ -444,12 +466,15 @@ def main():
                        "parallelism": "single GPU"},
             "model_years_per_day": round(cfg.model_years_per_day(steps_per_s), 1),
             "hip_event_ms_per_step": round(ev_ms / args.steps, 5),
+            "launch_mode": "HIP graphs: %d x 50-step + %d x 10-step blocks, %d eager steps" % (
+                args.steps // 50, (args.steps % 50) // 10, args.steps % 10),
             "state_finite": finite,
             "step_hbm_frac": round(56 * npts * 8.0 * (args.steps / (ev_ms * 1e-3)) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
                          "avg_launch_us": round(avg_us, 3), "algorithmic_bytes_per_launch": abytes,
-                         "frac_own_traffic": round(f_own * npts * 8.0 / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "reference_algorithm_bytes_per_launch": f_survey * npts * 8.0,
+                         "frac_reference_algorithm_bytes": round(f_survey * npts * 8.0 / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "measured_copy_GBps": round(copy_gbs, 1),
                          "event_bracket_us": {"subtracted_per_launch": round(bracket_us, 3),
                                               "calibration": "bracketed kernel times sum to the graph-replayed step time",

@@ -416,8 +416,37 @@ def test_full_size_steps_vs_oracle(natl5):
         sm, so = m.get_scalars(), o.get_scalars()
         scale = cfg.xlo * cfg.ylo * np.abs(po).max()
         assert np.abs(sm - so).max() / scale < 1e-13
+        check_against_reference_sample(m, "natl5", cfg, po, wek)
     finally:
         o.close()
+
+
+def check_against_reference_sample(m, name, cfg, po, wek, cyc=None):
+    """The same steps against the REFERENCE ITSELF at this size: tests/golden/<name>_sample.npz holds every
+    16th / 32nd row and column of the state after steps 1 and 4 of the true reference
+    (tests/golden/make_golden_fullsize.py), from the same synthetic inputs."""
+    g = load_golden(name + "_sample")
+    st = int(g["stride"])
+    assert np.array_equal(po[::st, ::st], g["in_po"]) and np.array_equal(wek[::st, ::st], g["in_wekpo"])
+    m.set_p(po, po)
+    m.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+    if cyc is not None:
+        assert cyc == (float(g["in_txis"]), float(g["in_txin"]))
+        m.set_cyc_forcing(*cyc)
+    done = 0
+    for s in (1, 4):
+        m.steps(s - done, s0=done + 1)
+        done = s
+        for i, f in enumerate(FIELDS):
+            x = m.get_state()[i]
+            err = np.abs(x[::st, ::st] - g["steps%d_%s" % (s, f)]).max() / float(g["steps%d_%s_max" % (s, f)])
+            assert err < TOL_CALL, (name, s, f, err)
+        sm, sr = m.get_scalars(), g["steps%d_scal" % s]
+        nl = cfg.nlo
+        scale = cfg.xlo * cfg.ylo * float(g["steps%d_po_max" % s])
+        assert np.abs(sm[:2 * (nl - 1)] - sr[:2 * (nl - 1)]).max() / scale < 1e-12
+        if cfg.cyclic:
+            assert relerr(sm[2 * (nl - 1):], sr[2 * (nl - 1):]) < 1e-10
 
 
 def test_full_size_long_run_is_finite_and_deterministic(natl5):
@@ -466,6 +495,7 @@ def test_full_size_socn5_cyclic_vs_oracle():
         assert relerr(sm[2 * (nl - 1):], so[2 * (nl - 1):]) < 1e-10
         m.steps(100, s0=4)  # exercises the graph path at this size
         assert all(np.isfinite(x).all() for x in m.get_state())
+        check_against_reference_sample(m, "socn5", cfg, po, wek, cyc=(txis, txin))
     finally:
         m.close()
         o.close()

@@ -125,3 +125,32 @@ def test_eigmod_vectors():
         # cm2l * cl2m = identity (the reference prints this check, eigmode.f:478-505)
         prod = e["ctm2loc"].T @ e["ctl2moc"].T
         assert np.abs(prod - np.eye(nl)).max() < 1e-14
+
+
+@pytest.mark.parametrize("name", ["natl5", "socn5"])
+def test_full_size_sample_from_the_reference(name):
+    """The C restatement at the FULL size of BASELINE configs[1] / [2] against the reference itself
+    (tests/golden/make_golden_fullsize.py: every 16th / 32nd row and column after steps 1 and 4)."""
+    from qgcm_hip import synth
+    cfg = preset(name)
+    g = load_golden(name + "_sample")
+    st = int(g["stride"])
+    po = synth.gaussian_eddy(cfg, noise=1e-3)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    assert np.array_equal(po[::st, ::st], g["in_po"]) and np.array_equal(wek[::st, ::st], g["in_wekpo"])
+    o = make_oracle(cfg)
+    try:
+        o.set_p(po, po)
+        o.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+        if cfg.cyclic:
+            o.set_cyc_forcing(float(g["in_txis"]), float(g["in_txin"]))
+        done = 0
+        for s in (1, 4):
+            o.steps(done + 1, s - done)
+            done = s
+            for i, n in enumerate(FIELDS):
+                x = o.get_state()[i]
+                assert np.abs(x[::st, ::st] - g["steps%d_%s" % (s, n)]).max() < 1e-12 * float(g["steps%d_%s_max" % (s, n)]), (s, n)
+    finally:
+        o.close()
