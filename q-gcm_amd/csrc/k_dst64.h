@@ -20,6 +20,7 @@
 #pragma once
 #include "qgcm_dev.h"
 #include "k_dst.h" // cplx helpers
+#include "k_misc.h" // constraint solve (k_dst64_unpack<.., CONSTR>)
 
 // The row transform is not required to be bitwise FFTPACK:
 // let the compiler fuse multiply-adds in this file only.
@@ -378,15 +379,43 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
 // The workgroups of the first / last interior row also write the wall rows (G = 1, nyg).
 // Reference: src/ocisubs.F:494-499 (inverse dsint), 377-401 (unpack), src/vorsubs.F:245-388.
 // grid: (npairs), block 64*NL.  HALO: also write the y-slab halo messages (whole-domain handles compile it out).
+// CONSTR: the mass-constraint solve (src/ocisubs.F:349-370) runs here too instead of in a launch of its own
+// (k_constr_box: 4-5 us of a 95 us step for 23 KB of work): the workgroup carries one EXTRA wave that forms the area
+// integrals from the spectral column sums of k_thomas and solves for hclco - redundantly in every workgroup, hidden
+// behind the transform of the other waves (the solve is a 2 us chain of dependent fp64 divides: done inside the
+// transforming waves it cost what the launch had saved) - and hands the coefficients over through LDS at the
+// barrier that follows the transform.  dpioc has been stepped by k_tend.  Workgroup 0 records xinhom / hclco.
+// Same functions as k_constr_box, contraction off: bitwise the same coefficients.
 // ---------------------------------------------------------------------------
-template <int M, int NL, bool BDY, bool HALO>
-__global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, const QgUnpackParams U, const QgBdyParams B) {
+template <int M, int NL, bool BDY, bool HALO, bool CONSTR>
+__global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(const QgDstParams P, const QgUnpackParams U,
+                                                                                const QgBdyParams B, const QgConstrLite C) {
   constexpr int N = 64 * M, NP = N + N / 16;
   __shared__ __align__(16) cplx Fsh[NL][M * D64_ROW];
   __shared__ __align__(16) cplx W64sh[NL][64];
+  __shared__ double hc_sh[NL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6; // = mode
+  if (CONSTR && wv == NL) { // the constraint wave
+    double xin[NL], dpn[NL - 1], x[NL - 1];
+    constr_xin<NL>(C, lane, xin);
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) dpn[k] = C.sc->dpioc[k];
+    constr_box_solve<NL>(C, xin, dpn, x);
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 1; m < NL; ++m) hc_sh[m] = x[m - 1];
+      if (blockIdx.x == 0) {
+#pragma unroll
+        for (int m = 0; m < NL; ++m) C.sc->xinhom[m] = xin[m];
+#pragma unroll
+        for (int k = 0; k < NL - 1; ++k) C.sc->hclco[k] = x[k];
+      }
+    }
+    __syncthreads(); // the barrier the transforming waves reach after dst64_core
+    return;
+  }
   const int ldw = P.g.ldw;
   const int ja = P.g.jr0 + 2 * blockIdx.x;     // local rows ja, ja+1 (grid is exactly the pairs)
   const bool has_b = (ja + 1 <= P.g.jr1);
@@ -422,14 +451,20 @@ __global__ __launch_bounds__(64 * NL) void k_dst64_unpack(const QgDstParams P, c
     ddw[r] = (BDY && ok) ? B.ddynoc[ow] : 0.0;
   }
   double hc[NL];
+  if (!CONSTR) {
 #pragma unroll
-  for (int m = 1; m < NL; ++m) hc[m] = U.sc->hclco[m - 1];
+    for (int m = 1; m < NL; ++m) hc[m] = U.sc->hclco[m - 1];
+  }
   {
     const double *rowa = P.wrk + P.g.wstride * wv + (long)(ja - 1) * ldw;
     double rsa, rsb;
     dst64_core<M>(P, rowa, rowa + ldw, has_b, Fsh[wv], W64sh[wv], lane, rsa, rsb);
   }
   __syncthreads();
+  if (CONSTR) {
+#pragma unroll
+    for (int m = 1; m < NL; ++m) hc[m] = hc_sh[m];
+  }
   const int nx = U.g.nx, nyg = U.g.nyg, joff = U.g.joff;
   // y-slab halo messages (k_halo_pack's layout: [k][3 rows][ldx] of p, then [k][ldx] of q): the first / last three
   // owned rows go to the lower / upper neighbour straight from here (no separate pack launch)

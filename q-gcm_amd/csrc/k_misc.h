@@ -40,19 +40,13 @@ __device__ inline double qg_block_sum(double v, double *red, int tid) {
   return r;
 }
 
-// One wavefront; NL is a template parameter so that every small array lives in
-// registers (run-time indexed locals would go to scratch memory and turn this
-// latency-bound kernel several times slower).
-template <int NL>
-__global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
-  const int lane = threadIdx.x;
-  constexpr int n1 = NL - 1;
+// Area integrals of the NL inhomogeneous solutions, xin(m) = dxo*dyo * sum_k wcot(k)*ksum(m,k), by ONE wave (every
+// lane returns the same values): only odd wavenumbers (even 0-based index) contribute; four independent partial
+// sums per lane keep four loads in flight (2400 terms per mode at 1 km); fixed order (s0 + s1) + (s2 + s3), then a
+// butterfly - deterministic, unlike the reference's OpenMP reduction.
+template <int NL, class PT>
+__device__ __forceinline__ void constr_xin(const PT &P, int lane, double *xin) {
   double s[NL];
-#pragma unroll
-  for (int m = 0; m < NL; ++m) s[m] = 0.0;
-  // area integrals from the spectral column sums: xintp(wrk_m) = sum_k wcot(k) * ksum(m,k)
-  // (k_thomas.h); only odd wavenumbers (even 0-based index) contribute. Four independent partial sums per lane
-  // keep four loads in flight (2400 terms per mode at 1 km); the order is fixed: (s0 + s1) + (s2 + s3).
   double s4[4][NL];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -69,31 +63,40 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
   }
 #pragma unroll
   for (int m = 0; m < NL; ++m) s[m] = (s4[0][m] + s4[1][m]) + (s4[2][m] + s4[3][m]);
-  // fixed-order butterfly: every lane ends with the same total
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
     for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
   }
-  if (lane != 0) return;
-  QgScalars *sc = P.sc;
-  double xin[NL], rhs[n1], x[n1], r[n1], w[n1];
 #pragma unroll
-  for (int m = 0; m < NL; ++m) {
-    xin[m] = s[m] * P.dxo * P.dyo;
-    sc->xinhom[m] = xin[m];
-  }
+  for (int m = 0; m < NL; ++m) xin[m] = s[m] * P.dxo * P.dyo;
+}
+
+// Leapfrog update of the mass-constraint integrals, src/ocisubs.F:343-347 (aient = xon(1) across the first
+// interface only). One thread.
+template <int NL>
+__device__ __forceinline__ void constr_dpi_update(QgScalars *sc, double tdto, const double *gpoc) {
 #pragma unroll
-  for (int k = 0; k < n1; ++k) {
+  for (int k = 0; k < NL - 1; ++k) {
     double aient = (k == 0) ? sc->xon[0] : 0.0;
     double aitmp = sc->dpioc[k];
-    double dpn = sc->dpiocp[k] - P.tdto * P.gpoc[k] * aient; // src/ocisubs.F:343-345
-    sc->dpioc[k] = dpn;
+    sc->dpioc[k] = sc->dpiocp[k] - tdto * gpoc[k] * aient;
     sc->dpiocp[k] = aitmp;
+  }
+}
+
+// rhs(k) = dpioc(k) - sum_m cdiffo(m,k)*xin(m) and the (nlo-1)x(nlo-1) solve with DGETRS + one DGERFS-style
+// refinement loop (src/ocisubs.F:349-370), host-side LU factors; dpn = the NEW dpioc.  -> hclco(1..nlo-1) in x.
+template <int NL, class PT>
+__device__ __forceinline__ void constr_box_solve(const PT &P, const double *xin, const double *dpn, double *x) {
+  constexpr int n1 = NL - 1;
+  double rhs[n1], r[n1], w[n1];
+#pragma unroll
+  for (int k = 0; k < n1; ++k) {
     double rhsum = 0.0;
 #pragma unroll
     for (int m = 0; m < NL; ++m) rhsum = rhsum + P.cs.cdiffo[m + NL * k] * xin[m];
-    rhs[k] = dpn - rhsum;
+    rhs[k] = dpn[k] - rhsum;
     x[k] = rhs[k];
   }
   // LU solve (DGETRS) with the host-side factors; pivots applied as selects
@@ -151,6 +154,27 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
     } else
       break;
   }
+}
+
+// One wavefront; NL is a template parameter so that every small array lives in
+// registers (run-time indexed locals would go to scratch memory and turn this
+// latency-bound kernel several times slower).  Inside qgcm_hip_steps the box ocean does without this launch:
+// the same functions run in k_tend (dpioc update) and in every workgroup of k_dst64_unpack<.., CONSTR>.
+template <int NL>
+__global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
+  const int lane = threadIdx.x;
+  constexpr int n1 = NL - 1;
+  double xin[NL];
+  constr_xin<NL>(P, lane, xin);
+  if (lane != 0) return;
+  QgScalars *sc = P.sc;
+#pragma unroll
+  for (int m = 0; m < NL; ++m) sc->xinhom[m] = xin[m];
+  constr_dpi_update<NL>(sc, P.tdto, P.gpoc);
+  double dpn[n1], x[n1];
+#pragma unroll
+  for (int k = 0; k < n1; ++k) dpn[k] = sc->dpioc[k];
+  constr_box_solve<NL>(P, xin, dpn, x);
 #pragma unroll
   for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
 }

@@ -29,6 +29,7 @@
 // q buffers rotate instead).
 #pragma once
 #include "qgcm_dev.h"
+#include "k_misc.h" // constr_dpi_update
 
 #ifndef TEND_TX
 #define TEND_TX 16
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   const int gx = T.gx, gy = T.gy;
   const int ntiles = gx * gy;
   const int per_xcd = (ntiles + 7) / 8;
+  if (!CYC && P.upd_dpi && blockIdx.x == 0 && tid == 0) constr_dpi_update<NL>(P.sc, P.tdto, P.gpoc); // see QgTendParams
   if ((int)blockIdx.x >= 8 * per_xcd) {
     tend_edge<NL>(P, T, (int)blockIdx.x - 8 * per_xcd);
     return;

@@ -64,6 +64,11 @@ struct QgTendParams {
   double adfaco, bcfaco, dxom2, tdto, bdrfac, fnot, beta;
   double fohfac[QG_MAXL], ah2fac[QG_MAXL], ah4fac[QG_MAXL];
   double ctl2m[QG_MAXL * QG_MAXL]; // (k,m) at k + nl*m
+  // box ocean inside qgcm_hip_steps: the leapfrog update of the mass-constraint integrals dpioc / dpiocp
+  // (src/ocisubs.F:343-347) is done here, by one thread, so that the constraint solve can run redundantly in every
+  // workgroup of the fused inverse-transform kernel (k_dst64_unpack<.., CONSTR>) without a launch of its own
+  int upd_dpi;
+  double gpoc[QG_MAXL];
 };
 
 struct QgDstParams {
@@ -115,6 +120,19 @@ struct QgBdyParams {
   double bcfaco_f0; // bccooc*dxom2/(0.5*bccooc+1)/fnot
   double beta;
   double f0A[QG_MAXL * QG_MAXL]; // fnot*amatoc(k,l) at k + nl*l
+};
+
+// what the box constraint solve needs, packed for nlo <= 4 (the kernels are instantiated for 2..4 layers): rides as a
+// fourth argument of k_dst64_unpack<.., CONSTR> - the full QgConstrParams would push the kernel arguments past 4 KB
+struct QgConstrLite {
+  QgGeom g;
+  const double *ksum, *wcot;
+  QgScalars *sc;
+  struct {
+    double cdiffo[16], cdhoc[16], cdhlu[16];
+    int ipiv[4];
+  } cs;
+  double dxo, dyo;
 };
 
 struct QgConstrParams {

@@ -69,6 +69,7 @@ struct qgcm_hip_ctx {
   bool dst_single = false; // generic row kernels run single-buffer (in-place) stages
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
+  bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
   hipError_t timer_err = hipSuccess;
@@ -232,6 +233,8 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     c->force_generic_dst = e && e[0] == '1';
     const char *f = getenv("QGCM_HIP_NO_FUSED_UNPACK");
     c->no_fused_unpack = f && f[0] == '1';
+    const char *fc = getenv("QGCM_HIP_NO_FUSED_CONSTR");
+    c->no_fused_constr = fc && fc[0] == '1';
   }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
@@ -628,7 +631,7 @@ static void drain_timers(qgcm_hip_ctx *c) {
   c->evkid.clear();
 }
 
-static int launch_tend(qgcm_hip_ctx *c) {
+static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
   QgTendParams P;
@@ -653,6 +656,8 @@ static int launch_tend(qgcm_hip_ctx *c) {
     P.ah4fac[k] = pr.ah4oc[k] / pr.fnot;
   }
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
+  P.upd_dpi = upd_dpi ? 1 : 0;
+  for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
   const TendTiling T = g.cyc ? tend_tiling<true>(g) : tend_tiling<false>(g);
   const int ntiles = T.gx * T.gy;
   dim3 grid(8 * ((ntiles + 7) / 8) + T.nedge); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge work
@@ -874,7 +879,8 @@ static bool can_fuse_dst_unpack(const qgcm_hip_ctx *c) {
          c->g.nl >= 2 && c->g.nl <= 4;
 }
 
-static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nullptr, double *msg_hi = nullptr) {
+static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nullptr, double *msg_hi = nullptr,
+                             bool constr = false) {
   const QgGeom &g = c->g;
   QgDstParams D;
   memset(&D, 0, sizeof(D));
@@ -896,13 +902,24 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nu
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
   QgBdyParams B;
   fill_bdy_params(c, B);
+  QgConstrLite C;
+  {
+    QgConstrParams F;
+    fill_constr_params(c, F);
+    memset(&C, 0, sizeof(C));
+    C.g = F.g; C.ksum = F.ksum; C.wcot = F.wcot; C.sc = F.sc;
+    C.dxo = F.dxo; C.dyo = F.dyo;
+    for (int i = 0; i < 16; ++i) { C.cs.cdiffo[i] = F.cs.cdiffo[i]; C.cs.cdhoc[i] = F.cs.cdhoc[i]; C.cs.cdhlu[i] = F.cs.cdhlu[i]; }
+    for (int i = 0; i < 4; ++i) C.cs.ipiv[i] = F.cs.ipiv[i];
+  }
   const int nrows = g.jr1 - g.jr0 + 1;
   dim3 grid((nrows + 1) / 2);
   KTimer t(c, KN_DSTI);
 #define QG_DU(MV, NLV)                                                                                                  \
-  if (msg_lo || msg_hi) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true>), grid, dim3(64 * NLV), 0, c->stream, D, P, B); \
-  else if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B);  \
-  else hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B)
+  if (msg_lo || msg_hi) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C); \
+  else if (fuse_bdy && constr) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
+  else if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C);  \
+  else hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, false, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C)
 #define QG_DU_NL(MV)                 \
   switch (g.nl) {                    \
     case 2: QG_DU(MV, 2); break;     \
@@ -971,16 +988,19 @@ extern "C" int qgcm_hip_qgostep(qgcm_hip_handle c) {
   return 0;
 }
 
-static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy) {
+// in_step: called from qgcm_hip_steps, where k_tend has already stepped dpioc / dpiocp (launch_tend(c, true)) and
+// the box constraint solve can ride in the fused inverse-transform kernel
+static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
   if (check_ready(c, "qgcm_hip_ocinvq")) return 1;
   if (!c->whole) QG_FAIL("qgcm_hip_ocinvq: this handle is a y-slab; drive it with the slab building blocks");
   if (!c->homog_set) QG_FAIL("qgcm_hip_ocinvq: homogeneous solutions not set");
   // (A per-mode side-stream variant of this chain was measured slower - 140 vs 116 us/step at 5 km - and removed.)
   if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
   if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
-  if (!c->g.cyc && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
+  const bool fused_constr = in_step && fuse_bdy && can_fuse_dst_unpack(c) && !c->no_fused_constr;
+  if (!c->g.cyc && !fused_constr && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
   if (can_fuse_dst_unpack(c)) {
-    if (launch_dst_unpack(c, fuse_bdy)) return 1;
+    if (launch_dst_unpack(c, fuse_bdy, nullptr, nullptr, fused_constr)) return 1;
     c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
     return 0;
   }
@@ -1242,8 +1262,11 @@ extern "C" int qgcm_hip_valids(qgcm_hip_handle c, double *out, int *solnok) {
 
 static int one_step(qgcm_hip_ctx *c, int s) {
   if (c->oml.on && launch_oml(c)) return 1; // src/q-gcm.F:1232
-  if (qgcm_hip_qgostep(c)) return 1;
-  if (ocinvq_impl(c, true)) return 1; // ocqbdy fused into the unpack kernel
+  const bool fused_constr = !c->g.cyc && can_fuse_dst_unpack(c) && !c->no_fused_constr; // see ocinvq_impl
+  if (check_ready(c, "qgcm_hip_steps")) return 1;
+  if (launch_tend(c, fused_constr)) return 1;
+  c->iq ^= 1; // as qgcm_hip_qgostep
+  if (ocinvq_impl(c, true, true)) return 1; // ocqbdy fused into the unpack kernel
   if ((s - 1) % c->avg_period == 0) {
     if (qgcm_hip_lf_average(c)) return 1; // incl. sst when the mixed layer is on
   }

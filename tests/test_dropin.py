@@ -78,5 +78,6 @@ def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_p
     # ocean steps from rest under wind (zero IC) / from radiative balance (coupled): free-running comparison
     # (tolerances: dropin_cases.RUNS)
     for k in ("po", "pom", "sst", "sstm") + (("pa", "pam", "ast", "astm", "hmixa", "hmixam") if mode == "coupled" else ()):
-        assert np.abs(ref[k]).max() > 0 or k == "pom", k   # (pom is still at rest after the first ocean step)
+        if nsteps > 1:   # (after one step from radiative balance the ocean is still at rest: po = pom = 0 in both)
+            assert np.abs(ref[k]).max() > 0, k
         assert relerr(got[k], ref[k]) < tol, (k, relerr(got[k], ref[k]))
