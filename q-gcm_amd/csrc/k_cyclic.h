@@ -7,7 +7,13 @@
 //                (:150-163).  They use the state BEFORE the step.
 //  k_constr_cyc  ocinvq's constraint algebra (src/ocisubs.F:169-294): line
 //                integrals ayis/ayin of the new modal solutions, c1, c2, c3,
-//                dpioc update, ocncs/ocncn leapfrog.
+//                dpioc update, ocncs/ocncn leapfrog.  All it needs of the new
+//                solution - the area integral and the sums of rows 2 and nypo-1 -
+//                is the zonal-mean (k = 0) column of the Thomas sweeps: the sum of
+//                a row over one period is nxto times its mean coefficient.  So the
+//                kernel runs BEFORE the inverse row transform (no row-sum pass over
+//                the transformed field) and the inverse transform can be fused with
+//                the unpack step.
 //  k_unpack_cyc  homogeneous corrections + modes->layers (src/ocisubs.F:300-327),
 //                optionally fused with ocqbdy (zonal boundaries only).
 #pragma once
@@ -29,13 +35,15 @@ __device__ __forceinline__ int cyc_col(int i, int nxt) {
 
 #define BSUM_NB 16 // blocks along x per (layer, side)
 
-// grid: (nl, 2, BSUM_NB): blockIdx.y = 0 south, 1 north; blockIdx.z = slice of columns.
-// 256 threads, fixed-order tree; the BSUM_NB partial sums per quantity are added, in block
-// order, by k_constr_cyc (deterministic).
-__global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
-  __shared__ double red[5][256];
+// One block of 256 threads = (layer k, side, slice of columns): nl * 2 * BSUM_NB blocks in all, block index
+// bidx = (k * 2 + north) * BSUM_NB + slice.  They ride at the end of the grid of k_tend<NL, true> (the sums use the
+// state BEFORE the step, which k_tend only reads), so the cyclic step has no launch for them.  Fixed-order
+// reduction (wave butterfly, then the four wave totals left to right); the BSUM_NB partial sums per quantity are
+// added, in block order, by k_constr_cyc (deterministic).
+__device__ __forceinline__ void cyc_bsums_block(const QgCycSumParams &P, int bidx) {
+  __shared__ double redw[5][4];
   const int tid = threadIdx.x;
-  const int k = blockIdx.x, north = blockIdx.y;
+  const int slice = bidx % BSUM_NB, north = (bidx / BSUM_NB) & 1, k = bidx / (2 * BSUM_NB);
   const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt, ldx = P.g.ldx;
   const long fs = P.g.fstride;
   const double *pom = P.pom + fs * k, *p = P.po + fs * k, *q = P.qo + fs * k;
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
   // two meridional neighbours differs from the reference (rounding level).
   double s5 = 0.0, s9 = 0.0, s3 = 0.0, s5d = 0.0, sb = 0.0;
   const int per = (nx + BSUM_NB - 1) / BSUM_NB;
-  const int ibeg = 1 + blockIdx.z * per, iend = min(nx, ibeg + per - 1);
+  const int ibeg = 1 + slice * per, iend = min(nx, ibeg + per - 1);
   for (int i = ibeg + tid; i <= iend; i += 256) {
     // Jacobian sums: weights 0.5 at i = 1 and i = nx (the same point), 1 inside
     const double wgt = (i == 1 || i == nx) ? 0.5 : 1.0;
@@ -71,16 +79,20 @@ __global__ __launch_bounds__(256) void k_cyc_bsums(const QgCycSumParams P) {
       if (k == P.g.nl - 1) sb += PM(i, 1) - PM(i, 0);
     }
   }
-  red[0][tid] = s5; red[1][tid] = s9; red[2][tid] = s3; red[3][tid] = s5d; red[4][tid] = sb;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off)
-      for (int v = 0; v < 5; ++v) red[v][tid] += red[v][tid + off];
-    __syncthreads();
+  double sv[5] = {s5, s9, s3, s5d, sb};
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int v = 0; v < 5; ++v) sv[v] += __shfl_xor(sv[v], off);
   }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int v = 0; v < 5; ++v) redw[v][tid >> 6] = sv[v];
+  }
+  __syncthreads();
   if (tid == 0) {
-    double *o = P.part + (((long)k * 2 + north) * BSUM_NB + blockIdx.z) * 5;
-    for (int v = 0; v < 5; ++v) o[v] = red[v][0];
+    double *o = P.part + (long)bidx * 5;
+    for (int v = 0; v < 5; ++v) o[v] = ((redw[v][0] + redw[v][1]) + redw[v][2]) + redw[v][3];
   }
 }
 
@@ -90,7 +102,7 @@ struct QgCycConstrParams {
   const double *bpart; // partial boundary line sums of k_cyc_bsums
   double adfaco, delek_sgn; // 1/(12 dxo dyo f0); 0.5*sign(f0)*delek
   double ah2oc[QG_MAXL], ah4oc[QG_MAXL];
-  const double *rowsum, *wrk;
+  const double *ksum, *wrk; // spectral column sums (k_thomas PHASE 0) and the solved spectral rows
   QgScalars *sc;
   QgConstr cs;
   double dxo, dyo, tdto, fnot;
@@ -103,24 +115,17 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
   const int lane = threadIdx.x;
   const int ny = P.g.ny;
   double s[NL], ys[NL], yn[NL];
-#pragma unroll
-  for (int m = 0; m < NL; ++m) s[m] = ys[m] = yn[m] = 0.0;
-  for (int j = P.g.jr0 - 1 + lane; j <= P.g.jr1 - 1; j += 64) {
-#pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += P.rowsum[(long)m * ny + j];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int m = 0; m < NL; ++m) s[m] += __shfl_xor(s[m], off);
-  }
-  // line integrals of the new modal solutions along rows 2 and nypo-1 (ocisubs.F:216-225):
-  // 0.5 w(1) + sum_{2..nx-1} + 0.5 w(nx) with w(nx) = w(1) is the sum over the nxto stored
-  // columns, i.e. exactly the row sum the inverse transform already delivered
+  // Sums over one period in x are nxto times the zonal-mean coefficient (spectral index 0 of the half-complex row;
+  // the Thomas sweep has already applied ftnorm = 1/nxto and the inverse transform is unnormalised):
+  //   area integral (xintp, ocisubs.F:160; rows 1 and nypo vanish): nxto * ksum(m, 0) - k_thomas's column sum;
+  //   line integrals along rows 2 and nypo-1 (ocisubs.F:216-225): 0.5 w(1) + sum_{2..nx-1} + 0.5 w(nx) with
+  //   w(nx) = w(1) is the sum over the nxto stored columns = nxto * wrk(k = 0, row).
+  const double xn = (double)P.g.nxt;
 #pragma unroll
   for (int m = 0; m < NL; ++m) {
-    ys[m] = P.rowsum[(long)m * ny + 1];
-    yn[m] = -P.rowsum[(long)m * ny + (ny - 2)];
+    s[m] = xn * P.ksum[(long)m * P.g.ldw];
+    ys[m] = xn * P.wrk[P.g.wstride * m + (long)1 * P.g.ldw];
+    yn[m] = -(xn * P.wrk[P.g.wstride * m + (long)(ny - 2) * P.g.ldw]);
   }
   // boundary line sums of the previous qgostep: lane (5*(2k+side) + v) adds the BSUM_NB block
   // partials of quantity v in block order (src/qgosubs.F:150-163, 279-297, 404-443)

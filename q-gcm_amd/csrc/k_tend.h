@@ -30,6 +30,7 @@
 #pragma once
 #include "qgcm_dev.h"
 #include "k_misc.h" // constr_dpi_update
+#include "k_cyclic.h" // cyc_bsums_block
 
 #ifndef TEND_TX
 #define TEND_TX 16
@@ -163,7 +164,7 @@ template <int NL, bool CYC>
 #ifndef TEND_WAVES_PER_EU
 #define TEND_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P) {
+__global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P, const QgCycSumParams S) {
   constexpr int TX = TEND_TX, TY = TEND_TY;
   constexpr int W3 = TX + 6, H3 = TY + 6; // pom tile, halo 3
   constexpr int W2 = TX + 4, H2 = TY + 4; // d2 tile, halo 2
@@ -193,7 +194,9 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   const int per_xcd = (ntiles + 7) / 8;
   if (!CYC && P.upd_dpi && blockIdx.x == 0 && tid == 0) constr_dpi_update<NL>(P.sc, P.tdto, P.gpoc); // see QgTendParams
   if ((int)blockIdx.x >= 8 * per_xcd) {
-    tend_edge<NL>(P, T, (int)blockIdx.x - 8 * per_xcd);
+    // cyclic / atmosphere: the boundary line sums for the momentum constraints (k_cyclic.h); box: the wall edges
+    if (CYC) cyc_bsums_block(S, (int)blockIdx.x - 8 * per_xcd);
+    else tend_edge<NL>(P, T, (int)blockIdx.x - 8 * per_xcd);
     return;
   }
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);

@@ -660,24 +660,22 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false) {
   for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
   const TendTiling T = g.cyc ? tend_tiling<true>(g) : tend_tiling<false>(g);
   const int ntiles = T.gx * T.gy;
-  dim3 grid(8 * ((ntiles + 7) / 8) + T.nedge); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge work
+  // cyclic: the boundary line sums for the momentum constraints (state before the step) ride as extra workgroups
+  QgCycSumParams S;
+  memset(&S, 0, sizeof(S));
   if (g.cyc) {
-    // boundary line sums for the momentum constraints, from the state before the step
-    QgCycSumParams S;
-    memset(&S, 0, sizeof(S));
     S.g = g;
     S.pom = P.pom; S.po = P.po; S.qo = P.qo;
     S.part = c->bpart;
     S.bcfaco = P.bcfaco; S.dxom2 = P.dxom2; S.adfaco = P.adfaco; S.fnot = pr.fnot;
     S.dxo = pr.dxo; S.dyo = pr.dyo;
-    KTimer tb(c, KN_BSUMS);
-    hipLaunchKernelGGL(k_cyc_bsums, dim3(g.nl, 2, BSUM_NB), dim3(256), 0, c->stream, S);
-    HIPCHECK(hipGetLastError());
   }
+  const int nextra = g.cyc ? g.nl * 2 * BSUM_NB : T.nedge;
+  dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
 #define QG_TEND(NLV)                                                                              \
-  if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true>), grid, dim3(TEND_NT), 0, c->stream, P);       \
-  else hipLaunchKernelGGL((k_tend<NLV, false>), grid, dim3(TEND_NT), 0, c->stream, P)
+  if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true>), grid, dim3(TEND_NT), 0, c->stream, P, S);    \
+  else hipLaunchKernelGGL((k_tend<NLV, false>), grid, dim3(TEND_NT), 0, c->stream, P, S)
   switch (g.nl) {
     case 2: QG_TEND(2); break;
     case 3: QG_TEND(3); break;
@@ -698,7 +696,7 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   P.wrk = wrk;
   P.twid = c->twid;
   P.sintab = c->sintab;
-  P.rowsum = (inverse && g.cyc) ? c->rowsum : nullptr; // box: area integrals come from k_thomas (ksum)
+  P.rowsum = nullptr; // area / line integrals come from k_thomas (ksum and the k = 0 column)
   P.N = c->fftN;
   P.nfac = c->nfac;
   for (int f = 0; f < c->nfac; ++f) P.fac[f] = c->fac[f];
@@ -786,7 +784,7 @@ static int launch_constr(qgcm_hip_ctx *c) {
     const qgcm_hip_params &pr2 = c->prm;
     QgCycConstrParams Q;
     memset(&Q, 0, sizeof(Q));
-    Q.g = g; Q.rowsum = c->rowsum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
+    Q.g = g; Q.ksum = c->ksum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
     Q.bpart = c->bpart;
     Q.adfaco = 1.0 / (12.0 * pr2.dxo * pr2.dyo * pr2.fnot);
     Q.delek_sgn = 0.5 * (pr2.fnot >= 0.0 ? 1.0 : -1.0) * pr2.delek;
@@ -998,14 +996,14 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
   if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
   if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   const bool fused_constr = in_step && fuse_bdy && can_fuse_dst_unpack(c) && !c->no_fused_constr;
-  if (!c->g.cyc && !fused_constr && launch_constr(c)) return 1; // box: area integrals are a by-product of the y sweeps
+  // area (and, cyclic, line) integrals are a by-product of the y sweeps: the constraints precede the inverse transform
+  if (!fused_constr && launch_constr(c)) return 1;
   if (can_fuse_dst_unpack(c)) {
     if (launch_dst_unpack(c, fuse_bdy, nullptr, nullptr, fused_constr)) return 1;
     c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
     return 0;
   }
   if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
-  if (c->g.cyc && launch_constr(c)) return 1; // cyclic: line and area sums of the transformed rows
   if (launch_unpack(c, fuse_bdy)) return 1;
   c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
   return 0;
