@@ -110,9 +110,105 @@ struct QgCycConstrParams {
   double ctl2m[QG_MAXL * QG_MAXL], ctm2l[QG_MAXL * QG_MAXL];
 };
 
+// Part A (one wave; needs the boundary line sums of this step's tendency launch): ajis.., ap3.., ap5.., bdrins;
+// right-hand sides of the momentum constraints and the leapfrog step of the constraint vectors
+// (src/ocisubs.F:176-206, src/atisubs.F:177-214).  Lane 0 updates the state; every lane returns the new vectors.
 template <int NL>
-__global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void constr_cyc_partA(const QgCycConstrParams &P, int lane, double *ocsnew, double *ocnnew) {
+  // boundary line sums of the previous qgostep: lane (5*(2k+side) + v) adds the BSUM_NB block
+  // partials of quantity v in block order (src/qgosubs.F:150-163, 279-297, 404-443)
+  double bs = 0.0;
+  if (lane < 10 * NL) {
+    const int ks = lane / 5, v = lane % 5;
+    for (int blk = 0; blk < BSUM_NB; ++blk) bs += P.bpart[((long)ks * BSUM_NB + blk) * 5 + v];
+  }
+  double bq[2 * NL][5];
+#pragma unroll
+  for (int ks = 0; ks < 2 * NL; ++ks)
+#pragma unroll
+    for (int v = 0; v < 5; ++v) bq[ks][v] = __shfl(bs, 5 * ks + v);
+  QgScalars *sc = P.sc;
+  const double fnot = P.fnot, tdto = P.tdto;
+  const double entfac = 0.5 * P.dyo * fnot * fnot;
+  double ajis[NL], ajin[NL], ap3s[NL], ap3n[NL], ap5s[NL], ap5n[NL], bdrins = 0.0, bdrinn = 0.0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    // south: sums as written; north: the reference's sums carry the opposite sign
+    // (qgosubs.F:409-420 Jacobian with leading minus; :436,438 "boundary minus inner")
+    const double *S = bq[2 * k], *Nn = bq[2 * k + 1];
+    ajis[k] = P.dxo * P.dyo * (fnot * P.adfaco * (S[0] + 2.0 * S[1]));
+    ajin[k] = P.dxo * P.dyo * (fnot * P.adfaco * (-Nn[0] + 2.0 * (-Nn[1])));
+    ap3s[k] = P.ah2oc[k] * S[2];
+    ap3n[k] = P.ah2oc[k] * (-Nn[2]);
+    ap5s[k] = P.ah4oc[k] * S[3];
+    ap5n[k] = P.ah4oc[k] * (-Nn[3]);
+    if (k == NL - 1) {
+      bdrins = P.delek_sgn * S[4];
+      bdrinn = P.delek_sgn * (-Nn[4]);
+    }
+  }
+  double enis[NL], enin[NL];
+#pragma unroll
+  for (int k = 0; k < NL - 1; ++k) {
+    enis[k] = sc->enisoc[k];
+    enin[k] = sc->eninoc[k];
+  }
+  const double txis = sc->txisoc, txin = sc->txinoc;
+  double rhss[NL], rhsn[NL];
+  if (P.g.atm) {
+    // atmosphere, src/atisubs.F:177-196: layer 1 is the bottom layer (stress and entrainment enter with the
+    // opposite sign), no Del-4th and no drag terms
+    rhss[0] = -(entfac / P.hoc[0]) * enis[0] - (fnot / P.hoc[0]) * txis + ajis[0] + ap5s[0];
+    rhsn[0] = -(entfac / P.hoc[0]) * enin[0] + (fnot / P.hoc[0]) * txin + ajin[0] - ap5n[0];
+#pragma unroll
+    for (int k = 1; k < NL - 1; ++k) {
+      rhss[k] = -(entfac / P.hoc[k]) * (enis[k] - enis[k - 1]) + ajis[k] + ap5s[k];
+      rhsn[k] = -(entfac / P.hoc[k]) * (enin[k] - enin[k - 1]) + ajin[k] - ap5n[k];
+    }
+    rhss[NL - 1] = (entfac / P.hoc[NL - 1]) * enis[NL - 2] + ajis[NL - 1] + ap5s[NL - 1];
+    rhsn[NL - 1] = (entfac / P.hoc[NL - 1]) * enin[NL - 2] + ajin[NL - 1] - ap5n[NL - 1];
+  } else {
+    // ocisubs.F:176-193
+    rhss[0] = (entfac / P.hoc[0]) * enis[0] + (fnot / P.hoc[0]) * txis + ajis[0] - ap3s[0] + ap5s[0];
+    rhsn[0] = (entfac / P.hoc[0]) * enin[0] - (fnot / P.hoc[0]) * txin + ajin[0] + ap3n[0] - ap5n[0];
+#pragma unroll
+    for (int k = 1; k < NL - 1; ++k) {
+      rhss[k] = (entfac / P.hoc[k]) * (enis[k] - enis[k - 1]) + ajis[k] - ap3s[k] + ap5s[k];
+      rhsn[k] = (entfac / P.hoc[k]) * (enin[k] - enin[k - 1]) + ajin[k] + ap3n[k] - ap5n[k];
+    }
+    rhss[NL - 1] = -(entfac / P.hoc[NL - 1]) * enis[NL - 2] + ajis[NL - 1] - ap3s[NL - 1] + ap5s[NL - 1] +
+                   (fnot / P.hoc[NL - 1]) * bdrins;
+    rhsn[NL - 1] = -(entfac / P.hoc[NL - 1]) * enin[NL - 2] + ajin[NL - 1] + ap3n[NL - 1] - ap5n[NL - 1] -
+                   (fnot / P.hoc[NL - 1]) * bdrinn;
+  }
+  // ocisubs.F:199-206
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    ocsnew[k] = sc->ocncsp[k] + tdto * rhss[k];
+    ocnnew[k] = sc->ocncnp[k] + tdto * rhsn[k];
+  }
+  if (lane != 0) return;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    sc->ajisoc[k] = ajis[k]; sc->ajinoc[k] = ajin[k];
+    sc->ap3soc[k] = ap3s[k]; sc->ap3noc[k] = ap3n[k];
+    sc->ap5soc[k] = ap5s[k]; sc->ap5noc[k] = ap5n[k];
+    sc->ocncsp[k] = sc->ocncs[k];
+    sc->ocncnp[k] = sc->ocncn[k];
+    sc->ocncs[k] = ocsnew[k];
+    sc->ocncn[k] = ocnnew[k];
+  }
+  sc->bdrins = bdrins;
+  sc->bdrinn = bdrinn;
+}
+
+// Part B (needs the Thomas sweeps): line and area integrals of the new modal solutions from the zonal-mean column,
+// c1, c2, c3 (src/ocisubs.F:212-244), area integrals of the layer pressures and the dpioc / dpiat update (:246-294).
+// ocsnew / ocnnew = the NEW constraint vectors (part A).  Every lane computes the same; `record`: lane 0 stores
+// xinhom, c1, c2, c3 and steps dpioc / dpiocp.
+template <int NL>
+__device__ __forceinline__ void constr_cyc_partB(const QgCycConstrParams &P, int lane, bool record, const double *ocsnew,
+                                                 const double *ocnnew, double *c1, double *c2, double &c3) {
   const int ny = P.g.ny;
   double s[NL], ys[NL], yn[NL];
   // Sums over one period in x are nxto times the zonal-mean coefficient (spectral index 0 of the half-complex row;
@@ -127,80 +223,9 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
     ys[m] = xn * P.wrk[P.g.wstride * m + (long)1 * P.g.ldw];
     yn[m] = -(xn * P.wrk[P.g.wstride * m + (long)(ny - 2) * P.g.ldw]);
   }
-  // boundary line sums of the previous qgostep: lane (5*(2k+side) + v) adds the BSUM_NB block
-  // partials of quantity v in block order (src/qgosubs.F:150-163, 279-297, 404-443)
-  double bs = 0.0;
-  if (lane < 10 * NL) {
-    const int ks = lane / 5, v = lane % 5;
-    for (int blk = 0; blk < BSUM_NB; ++blk) bs += P.bpart[((long)ks * BSUM_NB + blk) * 5 + v];
-  }
-  double bq[2 * NL][5];
+  double xin[NL], clhss[NL], clhsn[NL];
 #pragma unroll
-  for (int ks = 0; ks < 2 * NL; ++ks)
-#pragma unroll
-    for (int v = 0; v < 5; ++v) bq[ks][v] = __shfl(bs, 5 * ks + v);
-  if (lane != 0) return;
-  QgScalars *sc = P.sc;
-  const double fnot = P.fnot, tdto = P.tdto;
-  const double entfac = 0.5 * P.dyo * fnot * fnot;
-#pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    // south: sums as written; north: the reference's sums carry the opposite sign
-    // (qgosubs.F:409-420 Jacobian with leading minus; :436,438 "boundary minus inner")
-    const double *S = bq[2 * k], *Nn = bq[2 * k + 1];
-    sc->ajisoc[k] = P.dxo * P.dyo * (fnot * P.adfaco * (S[0] + 2.0 * S[1]));
-    sc->ajinoc[k] = P.dxo * P.dyo * (fnot * P.adfaco * (-Nn[0] + 2.0 * (-Nn[1])));
-    sc->ap3soc[k] = P.ah2oc[k] * S[2];
-    sc->ap3noc[k] = P.ah2oc[k] * (-Nn[2]);
-    sc->ap5soc[k] = P.ah4oc[k] * S[3];
-    sc->ap5noc[k] = P.ah4oc[k] * (-Nn[3]);
-    if (k == NL - 1) {
-      sc->bdrins = P.delek_sgn * S[4];
-      sc->bdrinn = P.delek_sgn * (-Nn[4]);
-    }
-  }
-  double xin[NL], rhss[NL], rhsn[NL], ocsnew[NL], ocnnew[NL], clhss[NL], clhsn[NL];
-#pragma unroll
-  for (int m = 0; m < NL; ++m) {
-    xin[m] = s[m] * P.dxo * P.dyo;
-    sc->xinhom[m] = xin[m];
-  }
-  if (P.g.atm) {
-    // atmosphere, src/atisubs.F:177-196: layer 1 is the bottom layer (stress and entrainment enter with the
-    // opposite sign), no Del-4th and no drag terms
-    rhss[0] = -(entfac / P.hoc[0]) * sc->enisoc[0] - (fnot / P.hoc[0]) * sc->txisoc + sc->ajisoc[0] + sc->ap5soc[0];
-    rhsn[0] = -(entfac / P.hoc[0]) * sc->eninoc[0] + (fnot / P.hoc[0]) * sc->txinoc + sc->ajinoc[0] - sc->ap5noc[0];
-#pragma unroll
-    for (int k = 1; k < NL - 1; ++k) {
-      rhss[k] = -(entfac / P.hoc[k]) * (sc->enisoc[k] - sc->enisoc[k - 1]) + sc->ajisoc[k] + sc->ap5soc[k];
-      rhsn[k] = -(entfac / P.hoc[k]) * (sc->eninoc[k] - sc->eninoc[k - 1]) + sc->ajinoc[k] - sc->ap5noc[k];
-    }
-    rhss[NL - 1] = (entfac / P.hoc[NL - 1]) * sc->enisoc[NL - 2] + sc->ajisoc[NL - 1] + sc->ap5soc[NL - 1];
-    rhsn[NL - 1] = (entfac / P.hoc[NL - 1]) * sc->eninoc[NL - 2] + sc->ajinoc[NL - 1] - sc->ap5noc[NL - 1];
-  } else {
-  // ocisubs.F:176-193
-  rhss[0] = (entfac / P.hoc[0]) * sc->enisoc[0] + (fnot / P.hoc[0]) * sc->txisoc + sc->ajisoc[0] - sc->ap3soc[0] + sc->ap5soc[0];
-  rhsn[0] = (entfac / P.hoc[0]) * sc->eninoc[0] - (fnot / P.hoc[0]) * sc->txinoc + sc->ajinoc[0] + sc->ap3noc[0] - sc->ap5noc[0];
-#pragma unroll
-  for (int k = 1; k < NL - 1; ++k) {
-    rhss[k] = (entfac / P.hoc[k]) * (sc->enisoc[k] - sc->enisoc[k - 1]) + sc->ajisoc[k] - sc->ap3soc[k] + sc->ap5soc[k];
-    rhsn[k] = (entfac / P.hoc[k]) * (sc->eninoc[k] - sc->eninoc[k - 1]) + sc->ajinoc[k] + sc->ap3noc[k] - sc->ap5noc[k];
-  }
-  rhss[NL - 1] = -(entfac / P.hoc[NL - 1]) * sc->enisoc[NL - 2] + sc->ajisoc[NL - 1] - sc->ap3soc[NL - 1] + sc->ap5soc[NL - 1] +
-                 (fnot / P.hoc[NL - 1]) * sc->bdrins;
-  rhsn[NL - 1] = -(entfac / P.hoc[NL - 1]) * sc->eninoc[NL - 2] + sc->ajinoc[NL - 1] + sc->ap3noc[NL - 1] - sc->ap5noc[NL - 1] -
-                 (fnot / P.hoc[NL - 1]) * sc->bdrinn;
-  }
-  // ocisubs.F:199-206
-#pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    ocsnew[k] = sc->ocncsp[k] + tdto * rhss[k];
-    ocnnew[k] = sc->ocncnp[k] + tdto * rhsn[k];
-    sc->ocncsp[k] = sc->ocncs[k];
-    sc->ocncnp[k] = sc->ocncn[k];
-    sc->ocncs[k] = ocsnew[k];
-    sc->ocncn[k] = ocnnew[k];
-  }
+  for (int m = 0; m < NL; ++m) xin[m] = s[m] * P.dxo * P.dyo;
   // ocisubs.F:212-234
 #pragma unroll
   for (int m = 0; m < NL; ++m) {
@@ -214,12 +239,19 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
     clhss[m] = cs + ayis;
     clhsn[m] = cn - ayin;
   }
-  const double c3 = clhss[0] * P.cs.hbsioc;
-  double c1[NL], c2[NL], aipmod[NL], aiplay[NL];
+  c3 = clhss[0] * P.cs.hbsioc;
 #pragma unroll
   for (int m = 0; m < NL - 1; ++m) {
     c1[m] = P.cs.hc2noc[m] * clhss[m + 1] - P.cs.hc2soc[m] * clhsn[m + 1];
     c2[m] = P.cs.hc1soc[m] * clhsn[m + 1] - P.cs.hc1noc[m] * clhss[m + 1];
+  }
+  if (!record || lane != 0) return;
+  QgScalars *sc = P.sc;
+  double aipmod[NL], aiplay[NL];
+#pragma unroll
+  for (int m = 0; m < NL; ++m) sc->xinhom[m] = xin[m];
+#pragma unroll
+  for (int m = 0; m < NL - 1; ++m) {
     sc->c1[m] = c1[m];
     sc->c2[m] = c2[m];
   }
@@ -240,6 +272,15 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
     sc->dpiocp[k] = sc->dpioc[k];
     sc->dpioc[k] = P.g.atm ? aiplay[k] - aiplay[k + 1] /* dpiat, src/atisubs.F:256 */ : aiplay[k + 1] - aiplay[k];
   }
+}
+
+// both parts in one launch (stand-alone atinvq / ocinvq, generic row sizes)
+template <int NL>
+__global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
+  const int lane = threadIdx.x;
+  double ocsnew[NL], ocnnew[NL], c1[NL], c2[NL], c3;
+  constr_cyc_partA<NL>(P, lane, ocsnew, ocnnew);
+  constr_cyc_partB<NL>(P, lane, true, ocsnew, ocnnew, c1, c2, c3);
 }
 
 // ---------------------------------------------------------------------------

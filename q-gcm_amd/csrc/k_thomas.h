@@ -26,6 +26,7 @@
 // Algorithmic traffic: read w + write u (16 B per point) for PHASE 0.
 #pragma once
 #include "qgcm_dev.h"
+#include "k_cyclic.h" // constr_cyc_partA
 
 #define TH_KW 16   // wavenumbers per workgroup (128-B line)
 #define TH_NC 64   // chunks per column
@@ -79,6 +80,18 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __shared__ double sD[TH_NC][TH_KW];
   __shared__ double sIn[TH_NC][TH_KW];
   const int tid = threadIdx.x;
+  if (PHASE == 0 && P.cycq && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup: part A of the cyclic / atmospheric constraint algebra, one wave
+    if (blockIdx.y == 0 && tid < 64) {
+      double a4[QG_MAXL], b4[QG_MAXL];
+      switch (P.g.nl) {
+        case 2: constr_cyc_partA<2>(*P.cycq, tid, a4, b4); break;
+        case 3: constr_cyc_partA<3>(*P.cycq, tid, a4, b4); break;
+        default: constr_cyc_partA<4>(*P.cycq, tid, a4, b4); break;
+      }
+    }
+    return;
+  }
   const int kk = tid % TH_KW;
   const int c = tid / TH_KW;
   const int lane = tid & 63, wv = tid >> 6;

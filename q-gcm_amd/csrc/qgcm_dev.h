@@ -99,6 +99,10 @@ struct QgThomasParams {
   const int *rconv;   // (ldw, nlayers): local row from which the pivot recurrence is bitwise stationary
   double aoc, ftnorm;
   int nlayers, layer0;
+  // cyclic / atmosphere inside qgcm_hip_steps: device copy of the constraint parameters; one extra workgroup
+  // (blockIdx.x == gridDim.x - 1) then runs part A of the constraint algebra (k_cyclic.h), which needs nothing of
+  // the sweeps, so that part B can ride in the fused inverse-transform kernel.  nullptr otherwise.
+  const struct QgCycConstrParams *cycq;
 };
 
 struct QgUnpackParams {

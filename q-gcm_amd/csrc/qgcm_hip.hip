@@ -18,6 +18,7 @@
 #include "k_thomas.h"
 #include "k_misc.h"
 #include "k_cyclic.h"
+#include "k_rfft64.h"
 #include "k_oml.h"
 #include "k_valids.h"
 #include "slab_comm.h"
@@ -55,7 +56,8 @@ struct qgcm_hip_ctx {
   int th_cgath_ranks = 0;
   double *ksum, *wcot;                     // spectral column sums of the solution and their cot weights (k_thomas.h)
   int *rconv, *rconv_tmp;                  // row from which the Thomas pivots are stationary
-  double *bpart;                           // cyclic: partial boundary line sums (k_cyc_bsums -> k_constr_cyc)
+  double *bpart;                           // cyclic: partial boundary line sums (k_tend's extra workgroups -> constraint algebra)
+  QgCycConstrParams *d_cycq = nullptr;     // cyclic: device copy of the constraint parameters (fused step path)
   int thR;                                 // rows per chunk of the Thomas kernel
   double *pch1, *pch2, *pbh;
   QgScalars *sc;
@@ -271,6 +273,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
   hipFree(c->sc);
+  if (c->d_cycq) hipFree(c->d_cycq);
   hipFree(c->rconv);
   hipFree(c->rconv_tmp);
   hipEventDestroy(c->ev0);
@@ -316,7 +319,9 @@ static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* 
 }
 
 static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
-                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st);
+                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st,
+                         bool cyc_part_a = false);
+static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q);
 
 extern "C" int qgcm_hip_set_geometry(qgcm_hip_handle c, const double *yporel, const double *ddynoc) {
   if (!c || !yporel) QG_FAIL("qgcm_hip_set_geometry: null argument");
@@ -467,6 +472,13 @@ extern "C" int qgcm_hip_set_homog_cyc(qgcm_hip_handle c, const double *pch1oc, c
   c->cs.hbsioc = hbsioc;
   c->cs.aipbho = aipbho;
   c->homog_set = true;
+  {
+    // device copy of the constraint parameters for the fused step path (k_thomas's extra workgroup, k_rfft64_unpack)
+    QgCycConstrParams Q;
+    fill_cyc_constr_params(c, Q);
+    if (!c->d_cycq) HIPCHECK(hipMalloc((void **)&c->d_cycq, sizeof(Q)));
+    HIPCHECK(hipMemcpy(c->d_cycq, &Q, sizeof(Q), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -709,8 +721,17 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
   if (g.cyc) {
-    if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true>), grid, dim3(RFFT_NT), c->dst_lds, st, P);
+    // wave-per-row-pair fast path when nxto = 64*M (k_rfft64.h); the generic Stockham kernel otherwise
+    const int M64 = (!c->force_generic_dst && c->fftN % 64 == 0) ? c->fftN / 64 : 0;
+#define QG_RF(MV)                                                                           \
+  if (inverse) hipLaunchKernelGGL((k_rfft64<MV, true>), grid64, dim3(D64_NT), 0, st, P);    \
+  else hipLaunchKernelGGL((k_rfft64<MV, false>), grid64, dim3(D64_NT), 0, st, P)
+    if (M64 == 3) { QG_RF(3); }
+    else if (M64 == 6) { QG_RF(6); }
+    else if (M64 == 15) { QG_RF(15); }
+    else if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true>), grid, dim3(RFFT_NT), c->dst_lds, st, P);
     else hipLaunchKernelGGL((k_rfft_cyc<false>), grid, dim3(RFFT_NT), c->dst_lds, st, P);
+#undef QG_RF
     HIPCHECK(hipGetLastError());
     return 0;
   }
@@ -726,7 +747,8 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
 }
 
 static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
-                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st) {
+                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st,
+                         bool cyc_part_a) {
   if (!st) st = c->stream;
   const QgGeom &g = c->g;
   QgThomasParams P;
@@ -747,6 +769,11 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
   P.nlayers = nlayers;
   P.layer0 = layer0;
   dim3 grid((g.nk + TH_KW - 1) / TH_KW, nlayers);
+  if (cyc_part_a) { // one extra workgroup: part A of the cyclic / atmospheric constraint algebra
+    if (phase != 0 || !c->d_cycq) QG_FAIL("k_thomas: part A of the constraint algebra needs the homogeneous solutions");
+    P.cycq = c->d_cycq;
+    grid.x += 1;
+  }
   KTimer t(c, KN_THOMAS, st);
 #define QG_TH(RV)                                                                                    \
   switch (phase) {                                                                                   \
@@ -781,20 +808,8 @@ static int launch_constr(qgcm_hip_ctx *c) {
   QgConstrParams P;
   fill_constr_params(c, P);
   if (g.cyc) {
-    const qgcm_hip_params &pr2 = c->prm;
     QgCycConstrParams Q;
-    memset(&Q, 0, sizeof(Q));
-    Q.g = g; Q.ksum = c->ksum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
-    Q.bpart = c->bpart;
-    Q.adfaco = 1.0 / (12.0 * pr2.dxo * pr2.dyo * pr2.fnot);
-    Q.delek_sgn = 0.5 * (pr2.fnot >= 0.0 ? 1.0 : -1.0) * pr2.delek;
-    for (int k = 0; k < g.nl; ++k) {
-      Q.ah2oc[k] = pr2.ah2oc[k];
-      Q.ah4oc[k] = pr2.ah4oc[k];
-    }
-    Q.dxo = P.dxo; Q.dyo = P.dyo; Q.tdto = P.tdto; Q.fnot = P.fnot;
-    for (int k = 0; k < QG_MAXL; ++k) { Q.gpoc[k] = P.gpoc[k]; Q.hoc[k] = P.hoc[k]; }
-    for (int i = 0; i < QG_MAXL * QG_MAXL; ++i) { Q.ctl2m[i] = P.ctl2m[i]; Q.ctm2l[i] = P.ctm2l[i]; }
+    fill_cyc_constr_params(c, Q);
     KTimer t(c, KN_CONSTR);
     switch (g.nl) {
       case 2: hipLaunchKernelGGL((k_constr_cyc<2>), dim3(1), dim3(64), 0, c->stream, Q); break;
@@ -814,6 +829,25 @@ static int launch_constr(qgcm_hip_ctx *c) {
   }
   HIPCHECK(hipGetLastError());
   return 0;
+}
+
+static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q) {
+  const QgGeom &g = c->g;
+  const qgcm_hip_params &pr2 = c->prm;
+  QgConstrParams P;
+  fill_constr_params(c, P);
+  memset(&Q, 0, sizeof(Q));
+  Q.g = g; Q.ksum = c->ksum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
+  Q.bpart = c->bpart;
+  Q.adfaco = 1.0 / (12.0 * pr2.dxo * pr2.dyo * pr2.fnot);
+  Q.delek_sgn = 0.5 * (pr2.fnot >= 0.0 ? 1.0 : -1.0) * pr2.delek;
+  for (int k = 0; k < g.nl; ++k) {
+    Q.ah2oc[k] = pr2.ah2oc[k];
+    Q.ah4oc[k] = pr2.ah4oc[k];
+  }
+  Q.dxo = P.dxo; Q.dyo = P.dyo; Q.tdto = P.tdto; Q.fnot = P.fnot;
+  for (int k = 0; k < QG_MAXL; ++k) { Q.gpoc[k] = P.gpoc[k]; Q.hoc[k] = P.hoc[k]; }
+  for (int i = 0; i < QG_MAXL * QG_MAXL; ++i) { Q.ctl2m[i] = P.ctl2m[i]; Q.ctm2l[i] = P.ctm2l[i]; }
 }
 
 static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P) {
@@ -867,6 +901,59 @@ static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
     default: QG_FAIL("k_unpack: unsupported nlo");
   }
 #undef QG_UNPACK
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// cyclic / atmosphere fast path: inverse rows + homogeneous corrections + modes -> layers (+ zonal-boundary PV) in
+// one launch (k_rfft64_unpack), nxto = 64 * {3, 6, 15}
+static bool can_fuse_rfft_unpack(const qgcm_hip_ctx *c) {
+  return c->g.cyc && c->whole && !c->force_generic_dst && !c->no_fused_unpack &&
+         (c->fftN == 64 * 3 || c->fftN == 64 * 6 || c->fftN == 64 * 15) && c->g.nl >= 2 && c->g.nl <= 4;
+}
+
+static int launch_rfft_unpack(qgcm_hip_ctx *c, bool fuse_bdy, bool constr) {
+  const QgGeom &g = c->g;
+  QgDstParams D;
+  memset(&D, 0, sizeof(D));
+  D.g = g;
+  D.wrk = c->wrk;
+  D.twid = c->twid;
+  D.N = c->fftN;
+  D.nlayers = g.nl;
+  QgUnpackParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.wrk = c->wrk;
+  P.pnew = c->p[c->ip ^ 1];
+  P.sc = c->sc;
+  P.pch1 = c->pch1; P.pch2 = c->pch2; P.pbh = c->pbh;
+  for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  QgBdyParams B;
+  fill_bdy_params(c, B);
+  if (constr && !c->d_cycq) QG_FAIL("k_rfft64_unpack: homogeneous solutions not set");
+  const int nrows = g.jr1 - g.jr0 + 1;
+  dim3 grid((nrows + 1) / 2);
+  KTimer t(c, KN_DSTI);
+#define QG_RU(MV, NLV)                                                                                                        \
+  if (fuse_bdy && constr) hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); \
+  else if (fuse_bdy) hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); \
+  else hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq)
+#define QG_RU_NL(MV)                 \
+  switch (g.nl) {                    \
+    case 2: QG_RU(MV, 2); break;     \
+    case 3: QG_RU(MV, 3); break;     \
+    default: QG_RU(MV, 4); break;    \
+  }
+  if (c->fftN == 64 * 15) {
+    QG_RU_NL(15)
+  } else if (c->fftN == 64 * 6) {
+    QG_RU_NL(6)
+  } else {
+    QG_RU_NL(3)
+  }
+#undef QG_RU_NL
+#undef QG_RU
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -994,6 +1081,16 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
   if (!c->homog_set) QG_FAIL("qgcm_hip_ocinvq: homogeneous solutions not set");
   // (A per-mode side-stream variant of this chain was measured slower - 140 vs 116 us/step at 5 km - and removed.)
   if (launch_dst(c, c->wrk, c->g.nl, false)) return 1;
+  if (c->g.cyc && can_fuse_rfft_unpack(c)) {
+    // cyclic / atmosphere, nxto = 64*M: inside qgcm_hip_steps part A of the constraint algebra rides in the Thomas
+    // launch and part B in the fused inverse-transform kernel (3 launches after k_tend instead of 5)
+    const bool fc = in_step && fuse_bdy && !c->no_fused_constr;
+    if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, fc)) return 1;
+    if (!fc && launch_constr(c)) return 1;
+    if (launch_rfft_unpack(c, fuse_bdy, fc)) return 1;
+    c->ip ^= 1;
+    return 0;
+  }
   if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   const bool fused_constr = in_step && fuse_bdy && can_fuse_dst_unpack(c) && !c->no_fused_constr;
   // area (and, cyclic, line) integrals are a by-product of the y sweeps: the constraints precede the inverse transform

@@ -620,3 +620,53 @@ def test_full_size_natl1_slabs_vs_oracle():
         for sl in slabs:
             sl.close()
         o.close()
+
+
+@pytest.mark.parametrize("name", ["cyc_med", "cyc_960"])
+def test_cyclic_fast_row_transform_vs_oracle(name):
+    """nxto = 64*3 / 64*15 zonally cyclic oceans: wave-per-row-pair real FFT rows (k_rfft64.h), constraint algebra split
+    over the Thomas launch and the fused inverse-transform / unpack kernel - against the CPU oracle, and the fused
+    step path against the stand-alone entry points (bitwise)."""
+    from qgcm_hip import OceanModel, synth
+    cfg = preset(name)
+    m = OceanModel(cfg)
+    o = make_oracle(cfg)
+    try:
+        po = synth.gaussian_eddy(cfg, noise=1e-3)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        txis, txin = synth.tau_line_integrals(cfg, tx)
+        enis, enin = np.full(cfg.nlo - 1, 1.0e-3), np.full(cfg.nlo - 1, 2.0e-3)
+        for mod in (m, o):
+            mod.set_p(po, 0.98 * po)
+            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+            mod.set_cyc_forcing(txis, txin, enis, enin)
+        m.steps(30, s0=1)
+        o.steps(1, 30)
+        for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
+            assert relerr(x, y) < 1e-10, f
+        sm, so = m.get_scalars(), o.get_scalars()
+        nl = cfg.nlo
+        scale = cfg.xlo * cfg.ylo * np.abs(po).max()
+        assert np.abs(sm[:2 * (nl - 1)] - so[:2 * (nl - 1)]).max() / scale < 1e-12
+        assert relerr(sm[2 * (nl - 1):], so[2 * (nl - 1):]) < 1e-9
+        a, sa = m.get_state(), m.get_scalars()
+        m.set_p(po, 0.98 * po)
+        for s in range(1, 31):
+            m.qgostep()
+            m.ocinvq()
+            m.ocqbdy()
+            if (s - 1) % 25 == 0:
+                m.lf_average()
+        for x, y in zip(a, m.get_state()):
+            assert np.array_equal(x, y)
+        assert np.array_equal(sa, m.get_scalars())
+        # Helmholtz solver alone (hscyoc) on a random right-hand side
+        rng = np.random.default_rng(5)
+        rhs = np.asfortranarray(rng.standard_normal((cfg.nxpo, cfg.nypo)))
+        rhs[-1, :] = rhs[0, :]
+        boc = m.bd2oc - m.rdm2oc[1]
+        assert relerr(m.helmholtz(rhs, boc), o.helmholtz(rhs, boc)) < TOL_CALL
+    finally:
+        m.close()
+        o.close()
