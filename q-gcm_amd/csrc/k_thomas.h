@@ -74,13 +74,15 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // grid: (ceil(nk/16), nlayers)
 #define TH_MSG 3
 #define TH_CST 4
-template <int R, int PHASE>
+// CYCA: the grid carries one extra workgroup for part A of the cyclic / atmospheric constraint algebra (a template
+// flag, not a run-time test: inlined into the plain instantiation the extra code cost it 11 spilled VGPRs at R = 16)
+template <int R, int PHASE, bool CYCA = false>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   __shared__ double sC[TH_NC][TH_KW];
   __shared__ double sD[TH_NC][TH_KW];
   __shared__ double sIn[TH_NC][TH_KW];
   const int tid = threadIdx.x;
-  if (PHASE == 0 && P.cycq && blockIdx.x == gridDim.x - 1) {
+  if (CYCA && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: part A of the cyclic / atmospheric constraint algebra, one wave
     if (blockIdx.y == 0 && tid < 64) {
       double a4[QG_MAXL], b4[QG_MAXL];

@@ -777,7 +777,10 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
   KTimer t(c, KN_THOMAS, st);
 #define QG_TH(RV)                                                                                    \
   switch (phase) {                                                                                   \
-    case 0: hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, st, P); break;        \
+    case 0:                                                                                          \
+      if (cyc_part_a) hipLaunchKernelGGL((k_thomas<RV, 0, true>), grid, dim3(TH_NT), 0, st, P);      \
+      else hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, st, P);                       \
+      break;                                                                                         \
     case 1: hipLaunchKernelGGL((k_thomas<RV, 1>), grid, dim3(TH_NT), 0, st, P); break;        \
     case 2: hipLaunchKernelGGL((k_thomas<RV, 2>), grid, dim3(TH_NT), 0, st, P); break;        \
     case 4: hipLaunchKernelGGL((k_thomas<RV, 4>), grid, dim3(TH_NT), 0, st, P); break;        \
