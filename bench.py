@@ -193,6 +193,57 @@ def pmc_traffic(kernel):
         return None
 
 
+def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p, nsteps, nwarm, bid):
+    """A secondary multi-GPU figure: the basin `cfg` cut into `world` y-slabs, one per rank, stepped by the driver
+    the headline measurement settled on (library-issued RCCL exchanges if they were verified there, else
+    torch.distributed).  Returns basin steps/s etc. (max over ranks); every rank must call it (collective)."""
+    import torch
+    import torch.distributed as dist
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import DistComm, HipSlab, SlabOcean, broadcast_unique_id, global_consts, partition
+    t_setup = time.perf_counter()
+    consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))  # init only, host
+    po = synth.gaussian_eddy(cfg)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+    scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+    g0, g1 = partition(cfg.nypo, world)[rank]
+    slab = HipSlab(cfg, consts, g0, g1, rank, world, device=local_rank)
+    torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
+    so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=not halo_p2p))
+    driver = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
+    if use_library:
+        so.use_library_exchanges(broadcast_unique_id(dist, slab.device))
+        slab.set_halo_p2p(halo_p2p)
+        driver = "library-issued RCCL (qgcm_hip_slab_steps)"
+    driver += ", halo rows by %s" % ("send/recv" if halo_p2p else "all-gather")
+    so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
+    del po, qo, wek, consts
+    t_setup = time.perf_counter() - t_setup
+    so.steps(nwarm, s0=1)
+    barrier()
+    t0 = time.perf_counter()
+    so.steps(nsteps, s0=nwarm + 1)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    (_, _, fields), = so.gather_local()
+    fin = torch.tensor([1.0 if all(np.isfinite(x).all() for x in fields) else 0.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())  # the slab's stream dies with the handle
+    slab.close()
+    wall = float(t.item())
+    sps = nsteps / wall
+    npts = cfg.nxpo * cfg.nypo
+    return {"basin_steps_per_s": round(sps, 2), "ms_per_step": round(1e3 * wall / nsteps, 5), "steps": nsteps, "warmup": nwarm,
+            "grid": [cfg.nxpo, cfg.nypo, cfg.nlo], "slab_rows": g1 - g0 + 1, "n_gpus": world, "dto_s": cfg.dto,
+            "model_years_per_day": round(cfg.model_years_per_day(sps), 1), "state_finite": bool(fin.item() > 0.5),
+            "step_hbm_frac_per_gpu": round(56 * npts * 8.0 * sps / world / 1e9 / HBM_PEAK_GBS, 4),
+            "exchange_driver": driver, "host_setup_s": round(t_setup, 1), "config": bid}
+
+
 def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     """N > 1: y-slab decomposition, one rank per GPU over RCCL (weak scaling).
 
@@ -241,6 +292,8 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
         return float(t.item()), bool(fin.item() > 0.5)
 
+    extra = {}   # secondary figures (filled after the headline measurement)
+
     def line(wall, finite, driver, library_exchanges="ok"):
         basin_sps = args.steps / wall
         npts = cfg5.nxpo * cfg5.nypo
@@ -262,7 +315,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             "library_exchanges": library_exchanges,   # "ok" | "not tried" | "stalled" (watchdog) | "failed"
             "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
             "step_hbm_frac_per_gpu": round(56 * npts * 8.0 * basin_sps / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": None, "cpu_baseline": None,
+            "roofline": None, "cpu_baseline": None, **extra,
         }) + "\n"
 
     # 1. The exchanges issued by Python (torch.distributed between the three stage calls): the plain, safe driver.
@@ -348,6 +401,40 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                 best = (wall_t, fin_t, drv_torch + "; library-issued driver: %.1f us/step" % (1e6 * wall_l / args.steps))
         dog.cancel()
     dist.barrier()
+    # ---- secondary figures: NOT `value`; same driver as the headline chose ------------------------------------------
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())  # the slab's stream dies with the handle
+    slab.close()
+    lib_ok = lib_status == "ok" and best[2].startswith("library")
+    p2p = "halo rows by send/recv" in best[2]
+    if os.environ.get("QGCM_BENCH_NO_SECONDARY") != "1":
+        import threading
+        from qgcm_hip import preset
+
+        def bail2():  # a stall in a secondary figure: the headline line goes out with the stall recorded, exit 3
+            extra["secondary_figures"] = "STALLED (watchdog fired)"
+            if rank == 0:
+                real_stdout.write(line(*best, library_exchanges=lib_status))
+                real_stdout.flush()
+            os._exit(3)
+        dog2 = threading.Timer(float(os.environ.get("QGCM_BENCH_WATCHDOG2_S", "420")), bail2)
+        dog2.daemon = True
+        dog2.start()
+        # (1) strong scaling: the FIXED NAtl 5 km basin (961 x 961 x 3, BASELINE configs[1]) cut into `world` slabs
+        try:
+            extra["strong_scaling_natl5"] = slab_secondary(cfg5, world, rank, local_rank, barrier, lib_ok, p2p, 400, 100,
+                                                           "double_gyre_ocean_only NAtl 5km, fixed basin over %d GPUs" % world)
+        except Exception as e:  # noqa: BLE001 - secondary figure only
+            extra["strong_scaling_natl5"] = {"error": repr(e)}
+        # (2) BASELINE configs[4]: NAtl 1 km (4801 x 4801 x 3, dto = 180 s) over the GPUs of the node; one slab may hold
+        #     at most 2048 interior rows (single-segment Thomas kernel), i.e. at least 3 GPUs
+        if world >= 3:
+            try:
+                extra["natl1km"] = slab_secondary(preset("natl1"), world, rank, local_rank, barrier, lib_ok, p2p, 100, 20,
+                                                  "NAtl 1km ocean-only, 3 layers, y-slabs over %d GPUs" % world)
+            except Exception as e:  # noqa: BLE001
+                extra["natl1km"] = {"error": repr(e)}
+        dog2.cancel()
     if rank == 0:
         real_stdout.write(line(*best, library_exchanges=lib_status))
         real_stdout.flush()

@@ -282,6 +282,23 @@ int qgcm_hip_oml_get_diag(qgcm_hip_handle h, double *entoc, double *diag);
 int qgcm_hip_set_dtopoc(qgcm_hip_handle h, const double *dtopoc);
 int qgcm_hip_valids(qgcm_hip_handle h, double *out, int *solnok);
 
+/* ---- start-up / restart arithmetic and the progress sample on the device ------------
+ * qgcm_hip_init_from_p: the start-up sequence of the main program (src/q-gcm.F:711-731; atmosphere :738-749) from
+ *   the po, pom ALREADY on the device (qgcm_hip_set_state with qo = qom = NULL, e.g. after a restart read):
+ *   constr (dpioc, dpiocp and, cyclic / atmosphere, ocncs, ocncn, ocncsp, ocncnp: src/conhoms.F:93-300), qcomp
+ *   (src/vorsubs.F:49-138), ocqbdy / atqzbd, merqcy (src/vorsubs.F:142-239) for both time levels.  qcomp / merqcy /
+ *   ocqbdy are bitwise the reference; the constraint integrals agree to rounding (parallel sums).
+ * qgcm_hip_wekpo_from_tau: ocean-only Ekman pumping from the wind stress tauxo, tauyo (nxpo,nypo) - wekto on the
+ *   T grid and its p-grid average wekpo (src/xfosubs.F:138, 566-645) - into the forcing the path reads (and
+ *   into the mixed layer's wekto / stress once qgcm_hip_oml_init was called).  Synchronous.
+ * qgcm_hip_prsamp: the ocean numbers of the progress print-out prsamp (src/q-gcm.F:1933-2066) without pulling the
+ *   state: out = po(k), qo(k) at the basin centre ((nxpo+1)/2, (nypo+1)/2), the layer averages pavgoc(k), qavgoc(k)
+ *   (src/monitor_diag.F:729-739), then min, max of sst (+-1e30 without the device mixed layer): 4*nlo + 2 doubles.
+ *   Synchronous. */
+int qgcm_hip_init_from_p(qgcm_hip_handle h);
+int qgcm_hip_wekpo_from_tau(qgcm_hip_handle h, const double *tauxo, const double *tauyo);
+int qgcm_hip_prsamp(qgcm_hip_handle h, double *out);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
  * the whole region, measured on the handle's stream. */

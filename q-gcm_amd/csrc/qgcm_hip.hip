@@ -21,6 +21,7 @@
 #include "k_rfft64.h"
 #include "k_oml.h"
 #include "k_valids.h"
+#include "k_setup.h"
 #include "slab_comm.h"
 
 static thread_local char g_err[512] = "";
@@ -96,6 +97,7 @@ struct qgcm_hip_ctx {
   } oml;
   // validity scan (qgcm_hip_valids): partials, results, optional bottom topography
   double *val_part = nullptr, *val_out = nullptr, *dtopoc = nullptr;
+  double *area_part = nullptr, *area_out = nullptr; // trapezoid area integrals of po, pom, qo (k_setup.h)
   // y-slab exchanges over RCCL (qgcm_hip_comm_init); slab-step graphs keyed like `graphs`
   QgSlabComm *sc_comm = nullptr;
   std::map<int, hipGraphExec_t> slab_graphs;
@@ -260,7 +262,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
       if (p) hipFree(p);
     delete m;
   }
-  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath};
+  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath, c->area_part, c->area_out};
   for (double *p : vp)
     if (p) hipFree(p);
   double *omp[] = {c->oml.sst[0], c->oml.sst[1], c->oml.sst[2], c->oml.fnet, c->oml.wekto, c->oml.xfo,
@@ -1355,6 +1357,149 @@ extern "C" int qgcm_hip_valids(qgcm_hip_handle c, double *out, int *solnok) {
   if (out)
     for (int q = 0; q < nres - 1; ++q) out[q] = h[q];
   if (solnok) *solnok = h[nres - 1] > 0.5 ? 1 : 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// start-up / restart arithmetic and the progress sample on the device
+// ---------------------------------------------------------------------------
+static int launch_area_sums(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  if (!c->area_part) {
+    if (dalloc(&c->area_part, (size_t)AREA_NB * 3 * QG_MAXL) || dalloc(&c->area_out, (size_t)3 * QG_MAXL)) return 1;
+  }
+  QgAreaParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.f[0] = c->p[c->ip]; P.f[1] = c->p[c->ip ^ 1]; P.f[2] = c->q[c->iq];
+  P.part = c->area_part; P.out = c->area_out;
+  switch (g.nl) {
+    case 2:
+      hipLaunchKernelGGL((k_area_partial<2>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);
+      hipLaunchKernelGGL((k_area_final<2>), dim3(1), dim3(64), 0, c->stream, P);
+      break;
+    case 3:
+      hipLaunchKernelGGL((k_area_partial<3>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);
+      hipLaunchKernelGGL((k_area_final<3>), dim3(1), dim3(64), 0, c->stream, P);
+      break;
+    default:
+      hipLaunchKernelGGL((k_area_partial<4>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);
+      hipLaunchKernelGGL((k_area_final<4>), dim3(1), dim3(64), 0, c->stream, P);
+      break;
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int qgcm_hip_init_from_p(qgcm_hip_handle c) {
+  if (check_ready(c, "qgcm_hip_init_from_p")) return 1;
+  if (!c->whole) QG_FAIL("qgcm_hip_init_from_p: only for a handle that owns the whole domain");
+  const QgGeom &g = c->g;
+  const qgcm_hip_params &pr = c->prm;
+  // constr: src/q-gcm.F:711
+  if (launch_area_sums(c)) return 1;
+  {
+    QgConstrInitParams P;
+    memset(&P, 0, sizeof(P));
+    P.g = g;
+    P.po = c->p[c->ip]; P.pom = c->p[c->ip ^ 1]; P.area = c->area_out; P.sc = c->sc;
+    P.dxo = pr.dxo; P.dyo = pr.dyo; P.fnot = pr.fnot;
+    for (int i = 0; i < g.nl * g.nl; ++i) P.amat[i] = pr.amatoc[i];
+    switch (g.nl) {
+      case 2: hipLaunchKernelGGL((k_constr_init<2>), dim3(1), dim3(64), 0, c->stream, P); break;
+      case 3: hipLaunchKernelGGL((k_constr_init<3>), dim3(1), dim3(64), 0, c->stream, P); break;
+      default: hipLaunchKernelGGL((k_constr_init<4>), dim3(1), dim3(64), 0, c->stream, P); break;
+    }
+    HIPCHECK(hipGetLastError());
+  }
+  // qcomp, ocqbdy / atqzbd, merqcy for both time levels: src/q-gcm.F:719-731, 738-749
+  for (int t = 0; t < 2; ++t) {
+    QgQcompParams Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.g = g;
+    Q.p = c->p[t ? c->ip ^ 1 : c->ip];
+    Q.q = c->q[t ? c->iq ^ 1 : c->iq];
+    Q.ddyn = c->ddynoc; Q.yporel = c->yporel;
+    Q.dx2fac = (1.0 / (pr.dxo * pr.dxo)) / pr.fnot;
+    Q.beta = pr.beta; Q.fnot = pr.fnot;
+    for (int i = 0; i < g.nl * g.nl; ++i) Q.amat[i] = pr.amatoc[i];
+    Q.ktopo = g.atm ? 0 : g.nl - 1;
+    hipLaunchKernelGGL(k_qcomp, dim3((g.nx + 255) / 256, g.ny - 2, g.nl), dim3(256), 0, c->stream, Q);
+    QgBdyParams B;
+    fill_bdy_params(c, B);
+    B.po = Q.p;
+    B.qo = Q.q;
+    const int nmax = g.nx > g.ny ? g.nx : g.ny;
+    hipLaunchKernelGGL(k_ocqbdy, dim3((nmax + 255) / 256, g.cyc ? 2 : 4, g.nl), dim3(256), 0, c->stream, B);
+    HIPCHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int qgcm_hip_wekpo_from_tau(qgcm_hip_handle c, const double *tauxo, const double *tauyo) {
+  if (check_ready(c, "qgcm_hip_wekpo_from_tau")) return 1;
+  if (!tauxo || !tauyo) QG_FAIL("qgcm_hip_wekpo_from_tau: null argument");
+  if (!c->whole) QG_FAIL("qgcm_hip_wekpo_from_tau: only for a handle that owns the whole domain");
+  const QgGeom &g = c->g;
+  const int nyt = g.ny - 1;
+  QgWekParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  double *tx = nullptr, *ty = nullptr, *wt = nullptr;
+  const bool own = !c->oml.on; // with the device mixed layer the stress and wekto live in its arrays
+  if (own) {
+    P.ldt = round_up(g.nxt, 16);
+    if (dalloc(&tx, (size_t)g.ldx * g.ny) || dalloc(&ty, (size_t)g.ldx * g.ny) || dalloc(&wt, (size_t)P.ldt * nyt)) return 1;
+  } else {
+    tx = c->oml.taux; ty = c->oml.tauy; wt = c->oml.wekto;
+    P.ldt = c->oml.ldt;
+  }
+  int rc = upload2d(c, tx, g.ldx, tauxo, g.nx, g.ny) || upload2d(c, ty, g.ldx, tauyo, g.nx, g.ny);
+  if (!rc) {
+    P.taux = tx; P.tauy = ty; P.wekto = wt; P.wekpo = c->wekpo;
+    P.hxofac = 0.5 * (1.0 / (c->prm.dxo * c->prm.fnot)); // src/xfosubs.F:138 with rdxof0 of src/q-gcm.F:435
+    hipLaunchKernelGGL(k_wekto, dim3((g.nxt + 255) / 256, nyt), dim3(256), 0, c->stream, P);
+    hipLaunchKernelGGL(k_wekpo, dim3((g.nx + 255) / 256, g.ny), dim3(256), 0, c->stream, P);
+    rc = hipGetLastError() != hipSuccess;
+    if (rc) snprintf(g_err, sizeof(g_err), "qgcm_hip_wekpo_from_tau: launch failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+  }
+  if (own) {
+    hipFree(tx); hipFree(ty); hipFree(wt);
+  }
+  return rc;
+}
+
+extern "C" int qgcm_hip_prsamp(qgcm_hip_handle c, double *out) {
+  if (check_ready(c, "qgcm_hip_prsamp")) return 1;
+  if (!out) QG_FAIL("qgcm_hip_prsamp: null argument");
+  if (!c->whole) QG_FAIL("qgcm_hip_prsamp: only for a handle that owns the whole domain");
+  const QgGeom &g = c->g;
+  const int nl = g.nl;
+  if (launch_area_sums(c)) return 1;
+  double area[3 * QG_MAXL];
+  HIPCHECK(hipMemcpyAsync(area, c->area_out, sizeof(double) * 3 * nl, hipMemcpyDeviceToHost, c->stream));
+  const int nxco = (g.nx + 1) / 2, nyco = (g.ny + 1) / 2; // src/q-gcm.F:1974-1975
+  const long oc = (long)(nyco - 1) * g.ldx + (nxco - 1);
+  for (int k = 0; k < nl; ++k) {
+    HIPCHECK(hipMemcpyAsync(out + k, c->p[c->ip] + g.fstride * k + oc, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(out + nl + k, c->q[c->iq] + g.fstride * k + oc, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  const double ocnorm = 1.0 / ((double)g.nxt * (double)(g.ny - 1)); // src/parameters_data.F:88
+  for (int k = 0; k < nl; ++k) {
+    out[2 * nl + k] = area[k] * ocnorm;          // pavgoc
+    out[3 * nl + k] = area[2 * nl + k] * ocnorm; // qavgoc
+  }
+  out[4 * nl] = 1.0e30;
+  out[4 * nl + 1] = -1.0e30;
+  if (c->oml.on) {
+    double v[14 + QG_MAXL];
+    int ok = 0;
+    if (qgcm_hip_valids(c, v, &ok)) return 1;
+    out[4 * nl] = v[4];     // min, max of sst (layout of qgcm_hip_valids)
+    out[4 * nl + 1] = v[5];
+  }
   return 0;
 }
 

@@ -113,6 +113,27 @@ class OceanModel:
         self.set_state(po, pom, qo, qom)
         self.set_scalars(hostinit.constr(c, self.amatoc, po, pom))
 
+    def init_from_p(self, po, pom=None):
+        """The same start-up sequence ON THE DEVICE (qgcm_hip_init_from_p): only po, pom cross PCIe - the restart
+        path of a host that keeps no q (restart dumps carry po, pom only, src/q-gcm.F:3076-3086)."""
+        po = _f(po)
+        pom = po if pom is None else _f(pom)
+        self.set_state(po, pom, None, None)
+        check(self.L.qgcm_hip_init_from_p(self.h))
+
+    def wekpo_from_tau(self, tauxo, tauyo):
+        """Ocean-only Ekman pumping from the wind stress on the device (src/xfosubs.F:566-645)."""
+        check(self.L.qgcm_hip_wekpo_from_tau(self.h, _dp(_f(tauxo)), _dp(_f(tauyo))))
+
+    def prsamp(self):
+        """The ocean numbers of the reference's progress print-out (src/q-gcm.F:1933-2066) without pulling the state:
+        dict(po_centre, qo_centre, pavgoc, qavgoc: nlo each; sstmin, sstmax)."""
+        nl = self.cfg.nlo
+        out = np.zeros(4 * nl + 2)
+        check(self.L.qgcm_hip_prsamp(self.h, _dp(out)))
+        return dict(po_centre=out[:nl].copy(), qo_centre=out[nl:2 * nl].copy(), pavgoc=out[2 * nl:3 * nl].copy(),
+                    qavgoc=out[3 * nl:4 * nl].copy(), sstmin=out[4 * nl], sstmax=out[4 * nl + 1])
+
     def set_state(self, po=None, pom=None, qo=None, qom=None):
         a = [_f(x) for x in (po, pom, qo, qom)]
         check(self.L.qgcm_hip_set_state(self.h, *[_dp(x) for x in a]))

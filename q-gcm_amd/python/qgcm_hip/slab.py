@@ -102,11 +102,30 @@ class DistComm:
         # latency-bound p2p launches on xGMI, and it uses a single collective type)
         self.halo_via_all_gather = halo_via_all_gather
         self._hsend = self._hgath = None
+        # gloo moves device tensors through the host and is not ordered on the slab's HIP stream (rehearsals of the
+        # multi-rank path on one GPU, CPU tests): bracket its collectives with device synchronisations. nccl = RCCL
+        # is stream-ordered and needs none.
+        self.host_staged = dist.get_backend(group) != "nccl"
+
+    def _fence(self):
+        if self.host_staged:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     def all_gather(self, gath, send):
+        self._fence()
         self.dist.all_gather_into_tensor(gath[0], send[0], group=self.group)
+        self._fence()
 
     def halo_exchange(self, to_lo, to_hi, from_lo, from_hi):
+        self._fence()
+        try:
+            return self._halo_exchange(to_lo, to_hi, from_lo, from_hi)
+        finally:
+            self._fence()
+
+    def _halo_exchange(self, to_lo, to_hi, from_lo, from_hi):
         if self.halo_via_all_gather:
             return self._halo_all_gather(to_lo, to_hi, from_lo, from_hi)
         d, r = self.dist, self.rank
