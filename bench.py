@@ -202,7 +202,7 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
     from qgcm_hip import hostinit, synth
     from qgcm_hip.slab import DistComm, HipSlab, SlabOcean, broadcast_unique_id, global_consts, partition
     t_setup = time.perf_counter()
-    consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))  # init only, host
+    consts = global_consts(cfg)  # eigmod, bd2oc, yporel (host, init only); homsol runs on the slabs below
     po = synth.gaussian_eddy(cfg)
     tx, ty = synth.wind_stress(cfg)
     _, wek = synth.wekpo_from_tau(cfg, tx, ty)
@@ -212,6 +212,7 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
     slab = HipSlab(cfg, consts, g0, g1, rank, world, device=local_rank)
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=not halo_p2p))
+    so.homsol()  # homogeneous solutions by the distributed Helmholtz solve itself (no host-side solver)
     driver = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
     if use_library:
         so.use_library_exchanges(broadcast_unique_id(dist, slab.device))
@@ -260,7 +261,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                                slab_slice)
 
     cfg = dataclasses.replace(cfg5, name="natl5_x%d" % world, nyaooc=cfg5.nyaooc * world, nyta=cfg5.nyta * world)
-    consts = global_consts(cfg, lambda w, b: hostinit.helmholtz_box_host(cfg, w, b))  # init only, host
+    consts = global_consts(cfg)  # eigmod, bd2oc, yporel (host, init only); homsol runs on the slabs below
     po = synth.gaussian_eddy(cfg)
     tx, ty = synth.wind_stress(cfg)
     _, wek = synth.wekpo_from_tau(cfg, tx, ty)
@@ -271,6 +272,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     # torch.distributed collectives are ordered on the library's own stream
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=True))
+    so.homsol()  # homogeneous solutions by the distributed Helmholtz solve itself (no host-side solver)
     zero2, xon0 = np.zeros_like(wek), np.zeros(cfg.nlo - 1)
 
     def local_state():

@@ -208,6 +208,16 @@ int qgcm_hip_halo_msg_len(qgcm_hip_handle h);
 int qgcm_hip_halo_pack(qgcm_hip_handle h, double *to_lower_dev, double *to_upper_dev);
 int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const double *from_upper_dev);
 
+/* homsol on y-slabs (src/conhoms.F:549-601 needs hsbxoc on the whole basin): the modal Helmholtz problems of a
+ * step ARE homsol's (boc = bd2oc - rdm2oc(m)), so the same distributed solve serves - fill the work array with the
+ * right-hand side 1 (qgcm_hip_wrk_fill), row_transform(0), thomas_phase 1 | exchange | 2, row_transform(1), read the
+ * solutions of the local rows back (qgcm_hip_wrk_get: (nxpo, nyl, nlo) block, walls and halo rows zero) and their
+ * basin-wide area integrals dxo*dyo*xintp(wrk_m) (qgcm_hip_area_integrals, from the spectral column sums of
+ * thomas_phase 2 / a whole-domain sweep; nlo doubles, synchronous).  No host-side solver is involved. */
+int qgcm_hip_wrk_fill(qgcm_hip_handle h, double value);
+int qgcm_hip_wrk_get(qgcm_hip_handle h, double *wrk);
+int qgcm_hip_area_integrals(qgcm_hip_handle h, double *xin);
+
 /* One call per communication-free stage of a distributed step (fewer host round trips):
  *   stage 1: qgostep, row_transform(0), thomas_phase(1)                          a = summary send buffer
  *   stage 2: thomas_phase(2), constr, row_transform(1), unpack(+ocqbdy), halo_pack

@@ -156,6 +156,22 @@ __device__ __forceinline__ void constr_box_solve(const PT &P, const double *xin,
   }
 }
 
+// area integrals only (homsol on y-slabs: qgcm_hip_area_integrals)
+template <int NL>
+__global__ __launch_bounds__(64) void k_xin_only(const QgConstrParams P) {
+  double xin[NL];
+  constr_xin<NL>(P, threadIdx.x, xin);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int m = 0; m < NL; ++m) P.sc->xinhom[m] = xin[m];
+}
+
+__global__ __launch_bounds__(256) void k_fill_rows(double *w, long wstride, int ldw, int nk, int j0, int j1, int nl, double v) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = j0 + blockIdx.y, m = blockIdx.z;
+  if (c < nk && j <= j1 && m < nl) w[wstride * m + (long)(j - 1) * ldw + c] = v;
+}
+
 // One wavefront; NL is a template parameter so that every small array lives in
 // registers (run-time indexed locals would go to scratch memory and turn this
 // latency-bound kernel several times slower).  Inside qgcm_hip_steps the box ocean does without this launch:

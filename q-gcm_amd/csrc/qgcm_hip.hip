@@ -155,7 +155,12 @@ static int download2d(qgcm_hip_ctx *c, double *dst, const double *src, int ld, i
 
 static int dalloc(double **p, size_t n) {
   HIPCHECK(hipMalloc((void **)p, n * sizeof(double)));
+  // The zero fill runs on the NULL stream, and a device memset need not have finished when hipMemset returns; the
+  // handle's stream is non-blocking (not ordered against the null stream), so work queued on it right after an
+  // allocation - the copy in qgcm_hip_set_thomas_consts, the all-gather in qgcm_hip_comm_init - could be overtaken
+  // by the fill and zeroed. Seen as wrong slab constants with three one-process-per-slab ranks. Wait for the fill.
   HIPCHECK(hipMemset(*p, 0, n * sizeof(double)));
+  HIPCHECK(hipStreamSynchronize(nullptr));
   return 0;
 }
 
@@ -1721,6 +1726,48 @@ extern "C" int qgcm_hip_local_rows(qgcm_hip_handle c, int *nyl, int *joff, int *
 extern "C" int qgcm_hip_row_transform(qgcm_hip_handle c, int inverse) {
   if (check_ready(c, "qgcm_hip_row_transform")) return 1;
   return launch_dst(c, c->wrk, c->g.nl, inverse != 0);
+}
+
+extern "C" int qgcm_hip_wrk_fill(qgcm_hip_handle c, double value) {
+  if (check_ready(c, "qgcm_hip_wrk_fill")) return 1;
+  const QgGeom &g = c->g;
+  HIPCHECK(hipMemsetAsync(c->wrk, 0, sizeof(double) * g.wstride * g.nl, c->stream));
+  hipLaunchKernelGGL(k_fill_rows, dim3((g.nk + 255) / 256, g.jr1 - g.jr0 + 1, g.nl), dim3(256), 0, c->stream, c->wrk,
+                     g.wstride, g.ldw, g.nk, g.jr0, g.jr1, g.nl, value);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int qgcm_hip_wrk_get(qgcm_hip_handle c, double *wrk) {
+  if (check_ready(c, "qgcm_hip_wrk_get")) return 1;
+  if (!wrk) QG_FAIL("qgcm_hip_wrk_get: null argument");
+  const QgGeom &g = c->g;
+  memset(wrk, 0, sizeof(double) * (size_t)g.nx * g.ny * g.nl);
+  const int coff = g.cyc ? 0 : 1;
+  for (int m = 0; m < g.nl; ++m)
+    HIPCHECK(hipMemcpy2DAsync(wrk + (size_t)g.nx * g.ny * m + (size_t)(g.jr0 - 1) * g.nx + coff, (size_t)g.nx * 8,
+                              c->wrk + g.wstride * m + (size_t)(g.jr0 - 1) * g.ldw, (size_t)g.ldw * 8, (size_t)g.nk * 8,
+                              (size_t)(g.jr1 - g.jr0 + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (g.cyc)
+    for (int m = 0; m < g.nl; ++m)
+      for (int j = 0; j < g.ny; ++j) wrk[((size_t)m * g.ny + j) * g.nx + g.nx - 1] = wrk[((size_t)m * g.ny + j) * g.nx];
+  return 0;
+}
+
+extern "C" int qgcm_hip_area_integrals(qgcm_hip_handle c, double *xin) {
+  if (check_ready(c, "qgcm_hip_area_integrals")) return 1;
+  if (!xin) QG_FAIL("qgcm_hip_area_integrals: null argument");
+  if (c->g.cyc) QG_FAIL("qgcm_hip_area_integrals: box ocean only (spectral area integrals of the sine series)");
+  QgConstrParams P;
+  fill_constr_params(c, P);
+  switch (c->g.nl) {
+    case 2: hipLaunchKernelGGL((k_xin_only<2>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 3: hipLaunchKernelGGL((k_xin_only<3>), dim3(1), dim3(64), 0, c->stream, P); break;
+    default: hipLaunchKernelGGL((k_xin_only<4>), dim3(1), dim3(64), 0, c->stream, P); break;
+  }
+  HIPCHECK(hipGetLastError());
+  return qgcm_hip_get_inv_diag(c, xin, nullptr);
 }
 
 extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? TH_MSG * c->g.nl * c->g.ldw : 0; }

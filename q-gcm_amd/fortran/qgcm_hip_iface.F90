@@ -140,6 +140,22 @@ module qgcm_hip_iface
       type(c_ptr), value :: oc, atm
       integer(c_int), value :: nt0, n, nstr
     end function
+    ! start-up / restart arithmetic and the progress sample on the device (src/q-gcm.F:711-731, 1933-2066;
+    ! src/xfosubs.F:566-645)
+    integer(c_int) function qgcm_hip_init_from_p(h) bind(C, name='qgcm_hip_init_from_p')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function qgcm_hip_wekpo_from_tau(h, tauxo, tauyo) bind(C, name='qgcm_hip_wekpo_from_tau')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: tauxo(*), tauyo(*)
+    end function
+    integer(c_int) function qgcm_hip_prsamp(h, out) bind(C, name='qgcm_hip_prsamp')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: out(*)
+    end function
     integer(c_int) function qgcm_hip_lf_average(h) bind(C, name='qgcm_hip_lf_average')
       import :: c_ptr, c_int
       type(c_ptr), value :: h

@@ -49,6 +49,7 @@ SYMBOLS = [
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_ocqbdy_host",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
     "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps",
+    "qgcm_hip_wrk_fill", "qgcm_hip_wrk_get", "qgcm_hip_area_integrals",
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
     "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
     "qgcm_hip_constr", "qgcm_hip_unpack",
@@ -101,6 +102,9 @@ def load_library():
     ip = C.POINTER(C.c_int)
     L.qgcm_hip_local_rows.argtypes = [vp, ip, ip, ip, ip]
     L.qgcm_hip_row_transform.argtypes = [vp, C.c_int]
+    L.qgcm_hip_wrk_fill.argtypes = [vp, C.c_double]
+    L.qgcm_hip_wrk_get.argtypes = [vp, dp]
+    L.qgcm_hip_area_integrals.argtypes = [vp, dp]
     L.qgcm_hip_thomas_msg_len.argtypes = [vp]
     L.qgcm_hip_thomas_const_len.argtypes = [vp]
     L.qgcm_hip_thomas_consts.argtypes = [vp, vp]

@@ -113,9 +113,18 @@ class DistComm:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
 
+    def _all_gather(self, gath, send):
+        if self.host_staged and send.is_cuda:  # gloo: explicit host staging (its device-tensor path is not reliable)
+            import torch
+            h = torch.empty(gath.numel(), dtype=gath.dtype)
+            self.dist.all_gather_into_tensor(h, send.cpu(), group=self.group)
+            gath.copy_(h)
+        else:
+            self.dist.all_gather_into_tensor(gath, send, group=self.group)
+
     def all_gather(self, gath, send):
         self._fence()
-        self.dist.all_gather_into_tensor(gath[0], send[0], group=self.group)
+        self._all_gather(gath[0], send[0])
         self._fence()
 
     def halo_exchange(self, to_lo, to_hi, from_lo, from_hi):
@@ -129,14 +138,24 @@ class DistComm:
         if self.halo_via_all_gather:
             return self._halo_all_gather(to_lo, to_hi, from_lo, from_hi)
         d, r = self.dist, self.rank
+        stage = self.host_staged and (to_lo[0] if to_lo[0] is not None else to_hi[0]).is_cuda
+        sl = (to_lo[0].cpu() if stage else to_lo[0]) if r > 0 else None
+        sh = (to_hi[0].cpu() if stage else to_hi[0]) if r < self.nranks - 1 else None
+        rl = (from_lo[0].cpu() if stage else from_lo[0]) if r > 0 else None
+        rh = (from_hi[0].cpu() if stage else from_hi[0]) if r < self.nranks - 1 else None
         ops = []
         if r > 0:
-            ops += [d.P2POp(d.isend, to_lo[0], r - 1, self.group), d.P2POp(d.irecv, from_lo[0], r - 1, self.group)]
+            ops += [d.P2POp(d.isend, sl, r - 1, self.group), d.P2POp(d.irecv, rl, r - 1, self.group)]
         if r < self.nranks - 1:
-            ops += [d.P2POp(d.isend, to_hi[0], r + 1, self.group), d.P2POp(d.irecv, from_hi[0], r + 1, self.group)]
+            ops += [d.P2POp(d.isend, sh, r + 1, self.group), d.P2POp(d.irecv, rh, r + 1, self.group)]
         if ops:
             for w in d.batch_isend_irecv(ops):
                 w.wait()
+        if stage:
+            if r > 0:
+                from_lo[0].copy_(rl)
+            if r < self.nranks - 1:
+                from_hi[0].copy_(rh)
 
     def _halo_all_gather(self, to_lo, to_hi, from_lo, from_hi):
         r, P = self.rank, self.nranks
@@ -149,7 +168,7 @@ class DistComm:
             self._hsend[:n].copy_(to_lo[0])
         if to_hi[0] is not None:
             self._hsend[n:].copy_(to_hi[0])
-        self.dist.all_gather_into_tensor(self._hgath, self._hsend, group=self.group)
+        self._all_gather(self._hgath, self._hsend)
         if r > 0:  # what the lower neighbour sent upwards
             from_lo[0].copy_(self._hgath[(2 * (r - 1) + 1) * n:(2 * (r - 1) + 2) * n])
         if r < P - 1:  # what the upper neighbour sent downwards
@@ -211,15 +230,32 @@ class HipSlab:
         bd2 = np.ascontiguousarray(consts["bd2oc"])
         dd = np.asfortranarray(consts["ddynoc"][:, sl])
         check(self.L.qgcm_hip_set_grid(self.h, _dp(yp), _dp(bd2), _dp(dd)))
-        oh = np.asfortranarray(consts["ochom"][:, sl, :])
-        cd, ch = np.asfortranarray(consts["cdiffo"]), np.asfortranarray(consts["cdhoc"])
-        check(self.L.qgcm_hip_set_homog_box(self.h, _dp(oh), _dp(cd), _dp(ch)))
+        self.consts = consts
+        if "ochom" in consts:  # global homogeneous solutions given; else SlabOcean.homsol() computes them on the slabs
+            self.set_homog(np.asfortranarray(consts["ochom"][:, sl, :]), consts["cdiffo"], consts["cdhoc"])
         self.sync_each_call = sync_each_call
         self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
         self.th_len = self.L.qgcm_hip_thomas_msg_len(self.h)
         self.cst_len = self.L.qgcm_hip_thomas_const_len(self.h)
         self.halo_len = self.L.qgcm_hip_halo_msg_len(self.h)
         self.stream_ptr = self.L.qgcm_hip_stream(self.h)
+
+    def set_homog(self, ochom_local, cdiffo, cdhoc):
+        oh, cd, ch = np.asfortranarray(ochom_local), np.asfortranarray(cdiffo), np.asfortranarray(cdhoc)
+        check(self.L.qgcm_hip_set_homog_box(self.h, _dp(oh), _dp(cd), _dp(ch)))
+
+    def wrk_fill(self, v):
+        check(self.L.qgcm_hip_wrk_fill(self.h, float(v))); self._done()
+
+    def wrk_get(self):
+        w = np.zeros((self.cfg.nxpo, self.nyl, self.cfg.nlo), order="F")
+        check(self.L.qgcm_hip_wrk_get(self.h, _dp(w)))
+        return w
+
+    def area_integrals(self):
+        x = np.zeros(self.cfg.nlo)
+        check(self.L.qgcm_hip_area_integrals(self.h, _dp(x)))
+        return x
 
     # buffers -------------------------------------------------------------
     def new_buffer(self, n):
@@ -378,6 +414,42 @@ class SlabOcean:
             for i, x in enumerate(S):  # halo rows in, leapfrog averaging every 25th step
                 x.stage(3, self.h_from_lo[i], self.h_from_hi[i], None, avg)
 
+    def homsol(self):
+        """homsol of the box ocean (src/conhoms.F:549-641) ON the slabs: the modal Helmholtz problems of a step are
+        homsol's, so one distributed solve with right-hand side 1 gives every ochom(:,:,m); no host-side solver.
+        Sets the homogeneous solutions on every local slab and returns the global products aipohs, cdiffo, cdhoc."""
+        cfg, S = self.cfg, self.slabs
+        nl = cfg.nlo
+        rdm2, cm2l = S[0].consts["rdm2oc"], S[0].consts["ctm2loc"]
+        for i, x in enumerate(S):
+            x.wrk_fill(1.0)
+            x.row_transform(0)
+            x.thomas_phase(1, None, self.th_send[i])
+        self._comm(self.comm.all_gather, self.th_gath, self.th_send)
+        sols, xin = [], None
+        for i, x in enumerate(S):
+            x.thomas_phase(2, self.th_gath[i], None)
+            xin = x.area_integrals()          # dxo*dyo*xintp(solution of mode m), basin-wide, the same on every rank
+            x.row_transform(1)
+            sols.append(x.wrk_get())
+        dA = cfg.dxo * cfg.dyo
+        aipohs = np.array([dA * cfg.nxto * cfg.nyto + rdm2[m + 1] * xin[m + 1] for m in range(nl - 1)])  # xintp(1) = nxto*nyto
+        cdiffo = np.zeros((nl, nl - 1), order="F")
+        cdhoc = np.zeros((nl - 1, nl - 1), order="F")
+        for k in range(nl - 1):
+            for m in range(nl):
+                cdiffo[m, k] = cm2l[m, k + 1] - cm2l[m, k]
+            for m in range(nl - 1):
+                cdhoc[k, m] = (cm2l[m + 1, k + 1] - cm2l[m + 1, k]) * aipohs[m]
+        for x, w in zip(S, sols):
+            oh = np.zeros((cfg.nxpo, x.nyl, nl - 1), order="F")
+            for m in range(nl - 1):
+                oh[:, :, m] = 1.0 + rdm2[m + 1] * w[:, :, m + 1]
+            # halo rows belong to the neighbours' solves; unpack only reads ochom on owned rows
+            x.set_homog(oh, cdiffo, cdhoc)
+            x.ochom_local = oh
+        return dict(aipohs=aipohs, cdiffo=cdiffo, cdhoc=cdhoc)
+
     def use_library_exchanges(self, comm_id):
         """From now on steps() runs qgcm_hip_slab_steps: the library issues the RCCL exchanges
         itself, Python is out of the step loop.  One slab per process; collective."""
@@ -412,12 +484,13 @@ class SlabOcean:
         return out
 
 
-def global_consts(cfg, helmholtz):
-    """Start-up constants on the GLOBAL grid (numpy, init-only), as in OceanModel."""
+def global_consts(cfg, helmholtz=None):
+    """Start-up constants on the GLOBAL grid (numpy, init-only), as in OceanModel.  helmholtz = None: without the
+    homogeneous solutions - SlabOcean.homsol() then computes them on the slabs (no host-side solver)."""
     A, rdm2, cl2m, cm2l = hostinit.eigmod(cfg.gpoc, cfg.hoc, cfg.fnot)
     aoc, bd2 = hostinit.bd2oc(cfg)
-    hom = hostinit.homsol_box(cfg, rdm2, cm2l, bd2, helmholtz)
     c = dict(amatoc=A, rdm2oc=rdm2, ctl2moc=cl2m, ctm2loc=cm2l, aoc=aoc, bd2oc=bd2, yporel=cfg.yporel(),
              ddynoc=np.zeros((cfg.nxpo, cfg.nypo), order="F"))
-    c.update(hom)
+    if helmholtz is not None:
+        c.update(hostinit.homsol_box(cfg, rdm2, cm2l, bd2, helmholtz))
     return c

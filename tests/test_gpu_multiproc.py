@@ -1,0 +1,24 @@
+"""One process per y-slab (the production layout: one process per GPU) rehearsed on ONE GPU: three processes share the
+card, torch.distributed/gloo carries the exchanges (RCCL refuses duplicate devices), and every process checks its slab
+BITWISE against the same decomposition run as virtual ranks.  Found in round 2: allocation zero-fills on the NULL
+stream overtaking copies queued on the handle's non-blocking stream (wrong slab constants with three ranks) - invisible
+to the virtual-rank tests, which synchronise after every call.  Needs an MI355X; 3 worker processes + this one."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("name,halo", [("box_small", "allgather"), ("box_small", "p2p"), ("box_med", "allgather")])
+def test_three_processes_one_slab_each(name, halo):
+    port = 29600 + (hash((name, halo)) % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "mp_slab_worker.py"), name, halo]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "MP_SLAB_RESULT OK" in r.stdout, r.stdout[-3000:]

@@ -670,3 +670,49 @@ def test_cyclic_fast_row_transform_vs_oracle(name):
     finally:
         m.close()
         o.close()
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+def test_homsol_on_y_slabs(nranks):
+    """homsol without a host-side solver: the distributed modal Helmholtz solve with right-hand side 1
+    (SlabOcean.homsol: qgcm_hip_wrk_fill, row transforms, the two Thomas phases around one exchange) against the
+    reference's ochom, aipohs, cdiffo, cdhoc (src/conhoms.F:549-611), then a few steps against the oracle."""
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition, slab_slice
+    cfg = preset("box_small")
+    g = load_golden("box_small")
+    o = make_oracle(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg)  # no helmholtz: no ochom
+        assert "ochom" not in consts
+        parts = partition(cfg.nypo, nranks)
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        hom = so.homsol()
+        for k in ("aipohs", "cdiffo", "cdhoc"):
+            assert relerr(hom[k], g["h_" + k]) < 1e-12, k
+        for x in slabs:
+            sl = slab_slice(cfg.nypo, x.g0, x.g1)
+            own = slice(x.jlo - 1, x.jhi)
+            assert relerr(x.ochom_local[:, own, :], g["h_ochom"][:, sl, :][:, own, :]) < 1e-12
+        po, pom = g["in_po"], g["in_pom"]
+        qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+        qom = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], pom)
+        scal = hostinit.constr(cfg, consts["amatoc"], po, pom)
+        so.scatter_state(po, pom, qo, qom, g["in_wekpo"], g["in_entoc"], g["in_xon"], scal)
+        o.set_p(po, pom)
+        o.set_forcing(g["in_wekpo"], g["in_entoc"], g["in_xon"])
+        so.steps(5, s0=1)
+        o.steps(1, 5)
+        got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+        for g0, g1, fields in so.gather_local():
+            for dst, src in zip(got, fields):
+                dst[:, g0 - 1:g1, :] = src
+        for f, x, y in zip(FIELDS, got, o.get_state()):
+            assert relerr(x, y) < 1e-11, (f, nranks)
+    finally:
+        for sl in slabs:
+            sl.close()
+        o.close()
