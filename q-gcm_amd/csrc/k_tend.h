@@ -208,33 +208,40 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   constexpr int RPT = TY / (TEND_NT / TX); // rows per thread
   const double bcf = P.bcfaco, dxom2 = P.dxom2;
 
-  // ---- global offsets of the elements this thread stages (same for every layer); recomputed where they are
-  // used instead of being kept in registers (the integer pipe has room, the register file has not)
-  auto off3 = [&](int e) -> long {
+  // ---- global offsets of the elements this thread stages (same for every layer), computed ONCE: 32-bit element
+  // offsets (the host checks ldx*ny*nl < 2^31) clamped to 0 where the element lies outside the array, plus a
+  // validity bit. Every staging load is then unconditional and followed by a select: a "load or zero" conditional
+  // makes hipcc branch around each load (exec-mask save / restore, s_cbranch_execz: ~560 of the kernel's 1900
+  // instructions were that bookkeeping, and the kernel is instruction-issue bound).
+  int o3[N3], o1[N1];
+  bool v3[N3], v1[N1];
+#pragma unroll
+  for (int e = 0; e < N3; ++e) {
     int idx = tid + e * TEND_NT;
     int lx = idx % W3, ly = idx / W3;
     int gi = i0 - 3 + lx, gj = j0 - 3 + ly;
-    bool ok = idx < H3 * W3 && gj >= 1 && gj <= ny && (CYC ? (gi >= -2 && gi <= nx + 3) : (gi >= 1 && gi <= nx));
-    return ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
-  };
-  auto off1 = [&](int e) -> long {
-    int idx = tid + e * TEND_NT;
-    int lx = idx % W1, ly = idx / W1;
-    int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
-    bool ok = idx < H1 * W1 && gj >= 1 && gj <= ny && (CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx));
-    return ok ? (long)(gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : -1;
-  };
-  double r3[N3], rp[N1], rq[N1];
-#pragma unroll
-  for (int e = 0; e < N3; ++e) {
-    const long o = off3(e);
-    r3[e] = o >= 0 ? P.pom[o] : 0.0;
+    v3[e] = idx < H3 * W3 && gj >= 1 && gj <= ny && (CYC ? (gi >= -2 && gi <= nx + 3) : (gi >= 1 && gi <= nx));
+    o3[e] = v3[e] ? (gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : 0;
   }
 #pragma unroll
   for (int e = 0; e < N1; ++e) {
-    const long o = off1(e);
-    rp[e] = o >= 0 ? P.po[o] : 0.0;
-    rq[e] = o >= 0 ? P.qo[o] : 0.0;
+    int idx = tid + e * TEND_NT;
+    int lx = idx % W1, ly = idx / W1;
+    int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
+    v1[e] = idx < H1 * W1 && gj >= 1 && gj <= ny && (CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx));
+    o1[e] = v1[e] ? (gj - 1) * ldx + (tend_wrap<CYC>(gi, nxt) - 1) : 0;
+  }
+  double r3[N3], rp[N1], rq[N1];
+#pragma unroll
+  for (int e = 0; e < N3; ++e) {
+    const double v = P.pom[o3[e]];
+    r3[e] = v3[e] ? v : 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < N1; ++e) {
+    const double a = P.po[o1[e]], b = P.qo[o1[e]];
+    rp[e] = v1[e] ? a : 0.0;
+    rq[e] = v1[e] ? b : 0.0;
   }
   // ---- epilogue operands of this thread's own points: requested while the LAST layer is computed (the
   // registers of the layer prefetch are free by then); the old qo of the wall rows is read in the epilogue
@@ -267,14 +274,14 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       const double *qo = P.qo + fs * (k + 1);
 #pragma unroll
       for (int e = 0; e < N3; ++e) {
-        const long o = off3(e);
-        r3[e] = o >= 0 ? pom[o] : 0.0;
+        const double v = pom[o3[e]];
+        r3[e] = v3[e] ? v : 0.0;
       }
 #pragma unroll
       for (int e = 0; e < N1; ++e) {
-        const long o = off1(e);
-        rp[e] = o >= 0 ? po[o] : 0.0;
-        rq[e] = o >= 0 ? qo[o] : 0.0;
+        const double a = po[o1[e]], b = qo[o1[e]];
+        rp[e] = v1[e] ? a : 0.0;
+        rq[e] = v1[e] ? b : 0.0;
       }
     } else {
 #pragma unroll
@@ -282,12 +289,12 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
         int ly = ty0 + r * (TEND_NT / TX);
         int gi = i0 + tx, gj = j0 + ly;
         bool in = gi <= T.imax && gj <= T.jmax;
-        long o = in ? (long)(gj - 1) * ldx + (gi - 1) : 0;
-        e_wek[r] = in ? P.wekpo[o] : 0.0;
-        e_ent[r] = in ? P.entoc[o] : 0.0;
-        e_ddy[r] = in ? P.ddynoc[o] : 0.0;
+        const int o = in ? (gj - 1) * ldx + (gi - 1) : 0; // clamped: unconditional loads, values unused when !in
+        e_wek[r] = P.wekpo[o];
+        e_ent[r] = P.entoc[o];
+        e_ddy[r] = P.ddynoc[o];
 #pragma unroll
-        for (int kk = 0; kk < NL; ++kk) e_qm[kk][r] = in ? P.qnew[fs * kk + o] : 0.0;
+        for (int kk = 0; kk < NL; ++kk) e_qm[kk][r] = P.qnew[fs * kk + o];
       }
     }
     // ---- Del^2(pom) on the halo-2 region (qgosubs.F:94-127) ----------
@@ -295,15 +302,16 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       int lx = idx % W2, ly = idx / W2;
       int gi = i0 - 2 + lx, gj = j0 - 2 + ly;
       const double *c = &sp[(ly + 1) * W3 + (lx + 1)];
-      double v = 0.0;
       bool inx = CYC ? (gi >= -1 && gi <= nx + 2) : (gi >= 1 && gi <= nx);
-      if (gj >= 1 && gj <= ny && inx) {
-        if (gj + joff == 1) v = bcf * (c[W3] - c[0]);
-        else if (gj + joff == nyg) v = bcf * (c[-W3] - c[0]);
-        else if (!CYC && gi == 1) v = bcf * (c[1] - c[0]);
-        else if (!CYC && gi == nx) v = bcf * (c[-1] - c[0]);
-        else v = (c[-W3] + c[-1] + c[1] + c[W3] - 4.0 * c[0]) * dxom2;
-      }
+      // branch-free: the wall rule picks ONE inner neighbour (N, S, E or W of a wall point), the interior rule is
+      // evaluated alongside and the result selected - same expressions, same rounding, no exec-mask bookkeeping
+      const double cS = c[-W3], cW = c[-1], c0 = c[0], cE = c[1], cN = c[W3];
+      const bool wS = (gj + joff == 1), wN = (gj + joff == nyg), wW = (!CYC && gi == 1), wE = (!CYC && gi == nx);
+      const double inner = wS ? cN : (wN ? cS : (wW ? cE : cW));
+      const double vw = bcf * (inner - c0);
+      const double vi = (cS + cW + cE + cN - 4.0 * c0) * dxom2;
+      double v = (wS || wN || wW || wE) ? vw : vi;
+      v = (gj >= 1 && gj <= ny && inx) ? v : 0.0;
       sd2[idx] = v;
     }
     __syncthreads();
@@ -312,15 +320,14 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       int lx = idx % W1, ly = idx / W1;
       int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
       const double *c = &sd2[(ly + 1) * W2 + (lx + 1)];
-      double v = 0.0;
       bool inx = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
-      if (gj >= 1 && gj <= ny && inx) {
-        if (gj + joff == 1) v = bcf * (c[W2] - c[0]);
-        else if (gj + joff == nyg) v = bcf * (c[-W2] - c[0]);
-        else if (!CYC && gi == 1) v = bcf * (c[1] - c[0]);
-        else if (!CYC && gi == nx) v = bcf * (c[-1] - c[0]);
-        else v = dxom2 * (c[-W2] + c[-1] + c[1] + c[W2] - 4.0 * c[0]);
-      }
+      const double cS = c[-W2], cW = c[-1], c0 = c[0], cE = c[1], cN = c[W2];
+      const bool wS = (gj + joff == 1), wN = (gj + joff == nyg), wW = (!CYC && gi == 1), wE = (!CYC && gi == nx);
+      const double inner = wS ? cN : (wN ? cS : (wW ? cE : cW));
+      const double vw = bcf * (inner - c0);
+      const double vi = dxom2 * (cS + cW + cE + cN - 4.0 * c0);
+      double v = (wS || wN || wW || wE) ? vw : vi;
+      v = (gj >= 1 && gj <= ny && inx) ? v : 0.0;
       sd4[idx] = v;
     }
     __syncthreads();
