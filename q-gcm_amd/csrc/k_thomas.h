@@ -78,9 +78,12 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // flag, not a run-time test: inlined into the plain instantiation the extra code cost it 11 spilled VGPRs at R = 16)
 template <int R, int PHASE, bool CYCA = false>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
-  __shared__ double sC[TH_NC][TH_KW];
-  __shared__ double sD[TH_NC][TH_KW];
-  __shared__ double sIn[TH_NC][TH_KW];
+  // pitch TH_KW + 1: the scans read / write these arrays transposed ([lane][wv]: 64 lanes at a stride of one row);
+  // at a pitch of 16 doubles = 128 B every lane hit the same pair of banks (SQ_LDS_BANK_CONFLICT was 55 % of the
+  // kernel's LDS cycles)
+  __shared__ double sC[TH_NC][TH_KW + 1];
+  __shared__ double sD[TH_NC][TH_KW + 1];
+  __shared__ double sIn[TH_NC][TH_KW + 1];
   const int tid = threadIdx.x;
   if (CYCA && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: part A of the cyclic / atmospheric constraint algebra, one wave
