@@ -210,9 +210,10 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
 
   // ---- global offsets of the elements this thread stages (same for every layer), computed ONCE: 32-bit element
   // offsets (the host checks ldx*ny*nl < 2^31) clamped to 0 where the element lies outside the array, plus a
-  // validity bit. Every staging load is then unconditional and followed by a select: a "load or zero" conditional
-  // makes hipcc branch around each load (exec-mask save / restore, s_cbranch_execz: ~560 of the kernel's 1900
-  // instructions were that bookkeeping, and the kernel is instruction-issue bound).
+  // validity bit. Every staging load is then unconditional: a "load or zero" conditional makes hipcc branch around
+  // each load (exec-mask save / restore, s_cbranch_execz: ~560 of the kernel's 1900 instructions were that
+  // bookkeeping, and the kernel is instruction-issue bound). Elements outside the array receive element 0 of the
+  // field - a finite value that no point inside the domain ever reads.
   int o3[N3], o1[N1];
   bool v3[N3], v1[N1];
 #pragma unroll
@@ -233,15 +234,43 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   }
   double r3[N3], rp[N1], rq[N1];
 #pragma unroll
-  for (int e = 0; e < N3; ++e) {
-    const double v = P.pom[o3[e]];
-    r3[e] = v3[e] ? v : 0.0;
+  for (int e = 0; e < N3; ++e) r3[e] = P.pom[o3[e]];
+#pragma unroll
+  for (int e = 0; e < N1; ++e) {
+    rp[e] = P.po[o1[e]];
+    rq[e] = P.qo[o1[e]];
+  }
+  // ---- the Del^2 / Del^4 passes of this thread (elements tid, tid + 256, ... of the halo-2 / halo-1 region): the LDS
+  // read base, the position of the ONE inner neighbour the wall rule uses (N of a S-wall point, ...) and whether the
+  // point is a wall point do not depend on the layer - computed once.  Points outside the domain are computed from
+  // whatever the (clamped) loads delivered: no point inside the domain ever reads them (interior points have all five
+  // neighbours inside, wall points read their inner neighbour only), so they need neither a predicate nor a select.
+  constexpr int N2 = (H2 * W2 + TEND_NT - 1) / TEND_NT;
+  int b2[N2], b4[N1], i2[N2], i4[N1];
+  bool w2[N2], w4[N1];
+#pragma unroll
+  for (int e = 0; e < N2; ++e) {
+    const int idx = tid + e * TEND_NT;
+    const int lx = idx % W2, ly = idx / W2;
+    const int gi = i0 - 2 + lx, gj = j0 - 2 + ly;
+    const bool inx = CYC ? (gi >= -1 && gi <= nx + 2) : (gi >= 1 && gi <= nx);
+    (void)inx;
+    b2[e] = (idx < H2 * W2) ? (ly + 1) * W3 + (lx + 1) : W3 + 1; // clamped: the extra pass reads valid LDS, stores nothing
+    const bool wS = (gj + joff == 1), wN = (gj + joff == nyg), wW = (!CYC && gi == 1), wE = (!CYC && gi == nx);
+    w2[e] = wS || wN || wW || wE;
+    i2[e] = b2[e] + (wS ? W3 : (wN ? -W3 : (wW ? 1 : -1)));
   }
 #pragma unroll
   for (int e = 0; e < N1; ++e) {
-    const double a = P.po[o1[e]], b = P.qo[o1[e]];
-    rp[e] = v1[e] ? a : 0.0;
-    rq[e] = v1[e] ? b : 0.0;
+    const int idx = tid + e * TEND_NT;
+    const int lx = idx % W1, ly = idx / W1;
+    const int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
+    const bool inx = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
+    (void)inx;
+    b4[e] = (idx < H1 * W1) ? (ly + 1) * W2 + (lx + 1) : W2 + 1;
+    const bool wS = (gj + joff == 1), wN = (gj + joff == nyg), wW = (!CYC && gi == 1), wE = (!CYC && gi == nx);
+    w4[e] = wS || wN || wW || wE;
+    i4[e] = b4[e] + (wS ? W2 : (wN ? -W2 : (wW ? 1 : -1)));
   }
   // ---- epilogue operands of this thread's own points: requested while the LAST layer is computed (the
   // registers of the layer prefetch are free by then); the old qo of the wall rows is read in the epilogue
@@ -273,15 +302,11 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       const double *po = P.po + fs * (k + 1);
       const double *qo = P.qo + fs * (k + 1);
 #pragma unroll
-      for (int e = 0; e < N3; ++e) {
-        const double v = pom[o3[e]];
-        r3[e] = v3[e] ? v : 0.0;
-      }
+      for (int e = 0; e < N3; ++e) r3[e] = pom[o3[e]];
 #pragma unroll
       for (int e = 0; e < N1; ++e) {
-        const double a = po[o1[e]], b = qo[o1[e]];
-        rp[e] = v1[e] ? a : 0.0;
-        rq[e] = v1[e] ? b : 0.0;
+        rp[e] = po[o1[e]];
+        rq[e] = qo[o1[e]];
       }
     } else {
 #pragma unroll
@@ -298,37 +323,27 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       }
     }
     // ---- Del^2(pom) on the halo-2 region (qgosubs.F:94-127) ----------
-    for (int idx = tid; idx < H2 * W2; idx += TEND_NT) {
-      int lx = idx % W2, ly = idx / W2;
-      int gi = i0 - 2 + lx, gj = j0 - 2 + ly;
-      const double *c = &sp[(ly + 1) * W3 + (lx + 1)];
-      bool inx = CYC ? (gi >= -1 && gi <= nx + 2) : (gi >= 1 && gi <= nx);
+#pragma unroll
+    for (int e = 0; e < N2; ++e) {
+      const int idx = tid + e * TEND_NT;
+      const double *c = &sp[b2[e]];
       // branch-free: the wall rule picks ONE inner neighbour (N, S, E or W of a wall point), the interior rule is
       // evaluated alongside and the result selected - same expressions, same rounding, no exec-mask bookkeeping
       const double cS = c[-W3], cW = c[-1], c0 = c[0], cE = c[1], cN = c[W3];
-      const bool wS = (gj + joff == 1), wN = (gj + joff == nyg), wW = (!CYC && gi == 1), wE = (!CYC && gi == nx);
-      const double inner = wS ? cN : (wN ? cS : (wW ? cE : cW));
-      const double vw = bcf * (inner - c0);
+      const double vw = bcf * (sp[i2[e]] - c0);
       const double vi = (cS + cW + cE + cN - 4.0 * c0) * dxom2;
-      double v = (wS || wN || wW || wE) ? vw : vi;
-      v = (gj >= 1 && gj <= ny && inx) ? v : 0.0;
-      sd2[idx] = v;
+      if (idx < H2 * W2) sd2[idx] = w2[e] ? vw : vi;
     }
     __syncthreads();
     // ---- Del^4 on the halo-1 region (qgosubs.F:310-341) ---------------
-    for (int idx = tid; idx < H1 * W1; idx += TEND_NT) {
-      int lx = idx % W1, ly = idx / W1;
-      int gi = i0 - 1 + lx, gj = j0 - 1 + ly;
-      const double *c = &sd2[(ly + 1) * W2 + (lx + 1)];
-      bool inx = CYC ? (gi >= 0 && gi <= nx + 1) : (gi >= 1 && gi <= nx);
+#pragma unroll
+    for (int e = 0; e < N1; ++e) {
+      const int idx = tid + e * TEND_NT;
+      const double *c = &sd2[b4[e]];
       const double cS = c[-W2], cW = c[-1], c0 = c[0], cE = c[1], cN = c[W2];
-      const bool wS = (gj + joff == 1), wN = (gj + joff == nyg), wW = (!CYC && gi == 1), wE = (!CYC && gi == nx);
-      const double inner = wS ? cN : (wN ? cS : (wW ? cE : cW));
-      const double vw = bcf * (inner - c0);
+      const double vw = bcf * (sd2[i4[e]] - c0);
       const double vi = dxom2 * (cS + cW + cE + cN - 4.0 * c0);
-      double v = (wS || wN || wW || wE) ? vw : vi;
-      v = (gj >= 1 && gj <= ny && inx) ? v : 0.0;
-      sd4[idx] = v;
+      if (idx < H1 * W1) sd4[idx] = w4[e] ? vw : vi;
     }
     __syncthreads();
     // ---- Del^6 + Jacobian at the tile's own points (qgosubs.F:349-399)
