@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root (gpurun -- 'bash profiles/collect.sh r1x'):
+# Run ON THE GPU BOX from the repo root (gpurun -- 'bash profiles/collect.sh r2x'):
 #   pass 1  rocprofv3 --kernel-trace --stats        of the default bench.py command -> kernel durations
 #   pass 2  rocprofv3 --pmc FETCH_SIZE              (own pass, kernel-trace only)
 #   pass 3  rocprofv3 --pmc WRITE_SIZE              (own pass)

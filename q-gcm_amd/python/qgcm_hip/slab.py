@@ -164,6 +164,9 @@ class DistComm:
         if self._hsend is None:
             self._hsend = ref.new_zeros(2 * n)
             self._hgath = ref.new_zeros(2 * n * P)
+            if ref.is_cuda:  # fills run on torch's current stream: settle before the slab's stream writes (SlabOcean._settle)
+                import torch
+                torch.cuda.synchronize()
         if to_lo[0] is not None:
             self._hsend[:n].copy_(to_lo[0])
         if to_hi[0] is not None:
@@ -378,11 +381,13 @@ class SlabOcean:
         self.h_to_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
         self.h_from_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
         self.h_from_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
+        self._settle()
         self.step_index = 1
         # the right-hand-side independent part of the slab summaries is exchanged once
         if self.P > 1:
             cs_send = [s.new_buffer(s.cst_len) for s in slabs]
             cs_gath = [s.new_buffer(s.cst_len * self.P) for s in slabs]
+            self._settle()
             for i, x in enumerate(slabs):
                 x.thomas_consts(cs_send[i])
             self._comm(comm.all_gather, cs_gath, cs_send)
@@ -390,6 +395,18 @@ class SlabOcean:
                 x.set_thomas_consts(cs_gath[i])
             for x in slabs:
                 x.sync()
+
+    @staticmethod
+    def _settle():
+        """torch zero-fills a new buffer on ITS current stream - the null stream unless the caller made the slab's
+        stream current - and the slabs' streams are non-blocking: not ordered against it.  A kernel that writes into a
+        fresh buffer could be overtaken by the fill.  Wait for the fills before the buffers are used."""
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:  # numpy-backed slabs of the CPU tests
+            pass
 
     def _comm(self, fn, *a):
         if self.stream_ctx is None:
