@@ -4,10 +4,14 @@
 //     aoc*u(j-1) + boc(i)*u(j) + aoc*u(j+1) = rhs(i,j),  j = 2..nypo-1
 // is solved by the Thomas algorithm (src/ocisubs.F:470-488 box, 575-593
 // cyclic) and scaled by ftnorm.  The pivots betinv(j) = 1/(boc - aoc*gam(j))
-// depend only on (boc, j).  The host tabulates the pivot entering each chunk
-// (same recurrence and rounding as the reference); every thread re-runs the
-// recurrence for its R rows (IEEE divides, identical values) while its row
-// loads are in flight, so no full-size pivot table is streamed.
+// depend only on (boc, j), and the recurrence reaches a bitwise fixed point after
+// a few rows (median 15 at 5 km; the lowest wavenumbers of the barotropic mode
+// never do).  The host runs the recurrence once (same operations and rounding as the
+// reference) and tabulates, per block of 16 wavenumbers, the pivots of the rows before
+// the block's last wavenumber has become stationary (< 1 MB at 5 km) plus the
+// stationary value per wavenumber: no divide is left in the kernel.  (Round 1
+// re-ran the recurrence per thread: the 16 IEEE divides of the never-stationary
+// block made that workgroup - and with it the launch - 4 us longer than the rest.)
 //
 // Parallel formulation: both sweeps are first-order linear recurrences
 //     forward : u_r = (w_r - aoc*u_{r-1}) * bet_r
@@ -107,42 +111,49 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const int ldw = P.g.ldw;
   const bool kok = k < P.g.nk;
   const double a = P.aoc;
-  double *wcol = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + k;
   const int r0 = c * R;
-  const bool first_rows = (P.g.jr0 + P.g.joff == 2); // slab starts at the first interior row
   const long msg = (long)TH_MSG * P.g.nl * ldw;
   const long mk = TH_MSG * ((long)m * ldw + kq);
   const double ft = P.ftnorm;
 
+  // 32-bit element offsets from a uniform base (one scalar pointer + one VGPR per address)
+  const double *wbase_c = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + blockIdx.x * TH_KW;
+  double *wbase = const_cast<double *>(wbase_c);
+  const unsigned off0 = (unsigned)(r0 * ldw + kk);
+  // rows past the end of the slab: PHASE 0 (whole column, zero inflow at both ends) pads them with w = 0, b = 0 - the
+  // forward values and the backward values of such rows are exactly 0, nothing of them is stored, and the sweeps need
+  // no per-row predicate.  The slab phases publish the value LEAVING the slab, so there padded rows must be the
+  // identity map: they keep the predicate.
+  constexpr bool PRED = (PHASE != 0);
   double w[R], b[R];
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     int r = r0 + t;
-    bool ok = kok && r < nr && PHASE != 4 && PHASE != 5;
-    w[t] = ok ? wcol[(long)r * ldw] : 0.0;
+    const bool ok = kok && r < nr && PHASE != 4 && PHASE != 5;
+    w[t] = ok ? wbase[off0 + (unsigned)(t * ldw)] : 0.0; // (unconditional loads at clamped offsets: 128 VGPRs + spills)
   }
-  // pivots of this chunk: betc = betinv of the row before the chunk (src/ocisubs.F:472-477).
-  // The recurrence reaches a bitwise fixed point after a few rows (median 15 at 5 km): from
-  // the global row rconv on every pivot equals betc, so most chunks need no divide at all.
+  // pivots of this chunk (src/ocisubs.F:472-477, tabulated by the host): rows below rcb from the block's table,
+  // the stationary value after that
   {
-    const double boc = kok ? P.boc[(long)m * ldw + k] : 1.0;
-    double betinv = kok ? P.betc[((long)m * TH_NC + c) * ldw + k] : 0.0;
-    const int rconv = kok ? P.rconv[(long)m * ldw + k] : 0; // local row from which the pivot is stationary
-    if (r0 >= rconv) {
+    const int tb = m * P.nblk + blockIdx.x;
+    const int rcb = P.rcb[tb];
+    const double binf = kok ? P.binf[(long)m * ldw + k] : 0.0;
 #pragma unroll
-      for (int t = 0; t < R; ++t) b[t] = (kok && r0 + t < nr) ? betinv : 0.0;
-    } else {
+    for (int t = 0; t < R; ++t) b[t] = binf;
+    if (r0 < rcb) {
+      const double *tab = P.ptab + (long)P.poff[tb] * TH_KW + kk;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
-        int r = r0 + t;
-        if (r == 0 && first_rows) {
-          betinv = 1.0 / boc;
-        } else {
-          double gam = a * betinv;
-          betinv = 1.0 / (boc - a * gam);
-        }
-        b[t] = (kok && r < nr) ? betinv : 0.0;
+        const int r = r0 + t;
+        const int rc = r < rcb ? r : rcb - 1;
+        const double v = tab[rc * TH_KW];
+        b[t] = (r < rcb && kok) ? v : binf;
       }
+    }
+    if (r0 + R > nr) {
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        if (r0 + t >= nr) b[t] = 0.0;
     }
   }
   // values entering the slab from the other ranks
@@ -173,15 +184,14 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     vin = __shfl(vin_s, P.rank);
     if (lane == 0 && kq < P.g.nk) P.ksum[(long)m * ldw + kq] = ft * term;
   }
-  // ---- forward: local affine maps (zero inflow); rows past the slab are the identity
-  // rows past the end of the slab are the identity map
-  constexpr bool PRED = true; // measured: dropping the row predicate for PHASE 0 is slower (22.4 vs 20.0 us)
+  // ---- forward: local affine maps (zero inflow); rows past the slab are the identity (PRED) or the zero map (PHASE 0)
+  // The chunk gain D = prod(-a*bet) is the same for both sweeps and is formed once (ascending rows).
   double C = 0.0, D = 1.0;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     if (!PRED || r0 + t < nr) {
       C = (w[t] - a * C) * b[t];
-      D = -a * b[t] * D;
+      D = -(a * b[t]) * D;
     }
   }
   sC[c][kk] = C;
@@ -204,22 +214,17 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
       u = (w[t] - a * u) * b[t];
       w[t] = u;
     }
+    b[t] = a * b[t]; // the backward sweep only needs a*bet
   }
-  __syncthreads(); // sC/sD/sIn are reused by the backward sweep
   // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
   C = 0.0;
-  D = 1.0;
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
-    if (!PRED || r0 + t < nr) {
-      C = w[t] - a * b[t] * C;
-      D = -a * b[t] * D;
-    }
+    if (!PRED || r0 + t < nr) C = w[t] - b[t] * C;
   }
-  sC[c][kk] = C;
-  sD[c][kk] = D;
+  sC[c][kk] = C; // safe without a barrier: every wave read the forward maps in sC before the barrier above
   __syncthreads();
-  // sweep order is last chunk first: lane l stands for chunk 63-l
+  // sweep order is last chunk first: lane l stands for chunk 63-l (sD still holds the chunk gains)
   const int cr = 63 - lane;
   Cs = sC[cr][wv];
   Ds = sD[cr][wv];
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
     if (!PRED || r0 + t < nr) {
-      v = w[t] - a * b[t] * v;
+      v = w[t] - b[t] * v;
       w[t] = v;
       colsum += v;
     }
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       int r = r0 + t;
-      if (kok && r < nr) wcol[(long)r * ldw] = ft * w[t];
+      if (kok && r < nr) wbase[off0 + (unsigned)(t * ldw)] = ft * w[t];
     }
   }
   if (PHASE == 2) return; // the basin-wide column sums came from the summaries

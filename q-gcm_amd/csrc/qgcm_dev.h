@@ -9,7 +9,7 @@
 //                 128-B aligned row of ldw doubles per (j,m):
 //                 box:    c = i-2  for interior i=2..nxpo-1 (nk = nxto-1 sine coeffs)
 //                 cyclic: c = i-1  for i=1..nxto            (nk = nxto, own spectral order)
-//   boc(c,m), betc(c,chunk,m)  Thomas diagonal and per-chunk entry pivots (small).
+//   Thomas pivot tables (QgThomasParams): small.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/qgcm_hip.h"
@@ -94,9 +94,12 @@ struct QgThomasParams {
   double *ksum;       // (ldw, nl): ftnorm * column sums of the solution per spectral index (see k_thomas.h)
   int rank, nranks;
   double *wrk;
-  const double *boc;  // (ldw, nlayers): tridiagonal diagonal per spectral index
-  const double *betc; // (ldw, TH_NC, nlayers): pivot entering each chunk of rows
-  const int *rconv;   // (ldw, nlayers): local row from which the pivot recurrence is bitwise stationary
+  // Thomas pivots, tabulated by the host (build_pivots): per block of 16 spectral indices the pivots of the local rows
+  // r < rcb (rcb = rows until the block's last index is bitwise stationary, >= 1), 16 doubles per row starting at row
+  // poff of ptab; binf (ldw, nlayers) = the stationary pivot per spectral index
+  const double *binf, *ptab;
+  const int *rcb, *poff; // (nblk, nlayers)
+  int nblk;
   double aoc, ftnorm;
   int nlayers, layer0;
   // cyclic / atmosphere inside qgcm_hip_steps: device copy of the constraint parameters; one extra workgroup

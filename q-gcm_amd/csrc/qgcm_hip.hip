@@ -42,6 +42,13 @@ enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK,
 static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_cyc_bsums", "k_dst_fwd", "k_thomas", "k_dst_inv",
                                              "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average", "k_oml", "k_noop", "k_noop_train"};
 
+// Device copy of the Thomas pivot tables of one set of diagonals (see QgThomasParams / build_pivots).
+struct QgThomasTab {
+  double *binf = nullptr, *ptab = nullptr;
+  int *rcb = nullptr, *poff = nullptr;
+  size_t binf_n = 0, ptab_n = 0, rcb_n = 0, poff_n = 0; // capacities (elements)
+};
+
 struct qgcm_hip_ctx {
   qgcm_hip_params prm;
   QgGeom g;
@@ -51,12 +58,11 @@ struct qgcm_hip_ctx {
   int ip, iq; // p[ip] = po, p[ip^1] = pom ; q[iq] = qo, q[iq^1] = qom
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
   double *wrk, *rowsum;
-  double *boc, *betc, *boc_tmp, *betc_tmp; // Thomas diagonal + chunk-entry pivots (per mode / scratch)
+  QgThomasTab tt, tt_tmp;                  // Thomas pivot tables of the modal solves / of the last qgcm_hip_helmholtz
   double *slabDE;                          // y-slab summary constants (D, E, SP, SQ) per (mode, wavenumber)
   double *th_cgath = nullptr;              // all ranks' slabDE (rank-major), exchanged once (qgcm_hip_set_thomas_consts)
   int th_cgath_ranks = 0;
   double *ksum, *wcot;                     // spectral column sums of the solution and their cot weights (k_thomas.h)
-  int *rconv, *rconv_tmp;                  // row from which the Thomas pivots are stationary
   double *bpart;                           // cyclic: partial boundary line sums (k_tend's extra workgroups -> constraint algebra)
   QgCycConstrParams *d_cycq = nullptr;     // cyclic: device copy of the constraint parameters (fused step path)
   int thR;                                 // rows per chunk of the Thomas kernel
@@ -220,16 +226,10 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->ochom, F * (g.nl - 1))) return 1;
   if (dalloc(&c->yporel, g.ny)) return 1;
   if (dalloc(&c->wrk, W * g.nl)) return 1;
-  if (dalloc(&c->boc, (size_t)g.ldw * g.nl) || dalloc(&c->betc, (size_t)g.ldw * TH_NC * g.nl)) return 1;
-  if (dalloc(&c->boc_tmp, (size_t)g.ldw) || dalloc(&c->betc_tmp, (size_t)g.ldw * TH_NC)) return 1;
   if (dalloc(&c->slabDE, (size_t)4 * g.ldw * g.nl)) return 1;
   if (dalloc(&c->ksum, (size_t)g.ldw * g.nl)) return 1;
   if (dalloc(&c->wcot, (size_t)g.ldw)) return 1;
   if (dalloc(&c->bpart, (size_t)5 * BSUM_NB * 2 * g.nl)) return 1;
-  HIPCHECK(hipMalloc((void **)&c->rconv, sizeof(int) * g.ldw * g.nl));
-  HIPCHECK(hipMalloc((void **)&c->rconv_tmp, sizeof(int) * g.ldw));
-  HIPCHECK(hipMemset(c->rconv, 0, sizeof(int) * g.ldw * g.nl));
-  HIPCHECK(hipMemset(c->rconv_tmp, 0, sizeof(int) * g.ldw));
   if (dalloc(&c->rowsum, (size_t)g.ny * g.nl)) return 1;
   if (dalloc(&c->pch1, (size_t)g.ny * g.nl) || dalloc(&c->pch2, (size_t)g.ny * g.nl) || dalloc(&c->pbh, g.ny)) return 1;
   HIPCHECK(hipMalloc((void **)&c->sc, sizeof(QgScalars)));
@@ -275,14 +275,18 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   for (double *p : omp)
     if (p) hipFree(p);
   double *ptrs[] = {c->p[0], c->p[1], c->q[0], c->q[1], c->wekpo, c->entoc, c->ddynoc, c->ochom, c->yporel,
-                    c->wrk,  c->boc,  c->betc, c->boc_tmp, c->betc_tmp, c->slabDE, c->ksum, c->wcot, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
+                    c->wrk,  c->slabDE, c->ksum, c->wcot, c->bpart, c->rowsum, c->pch1, c->pch2, c->pbh, c->sintab};
   for (double *p : ptrs)
     if (p) hipFree(p);
   if (c->twid) hipFree(c->twid);
   hipFree(c->sc);
   if (c->d_cycq) hipFree(c->d_cycq);
-  hipFree(c->rconv);
-  hipFree(c->rconv_tmp);
+  for (QgThomasTab *t : {&c->tt, &c->tt_tmp}) {
+    if (t->binf) hipFree(t->binf);
+    if (t->ptab) hipFree(t->ptab);
+    if (t->rcb) hipFree(t->rcb);
+    if (t->poff) hipFree(t->poff);
+  }
   hipEventDestroy(c->ev0);
   hipEventDestroy(c->ev1);
   for (hipEvent_t e : c->evpool) hipEventDestroy(e);
@@ -298,34 +302,72 @@ static int thomas_rows_per_chunk(int nrows) {
   return -1;
 }
 
-// Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477; only the pivot
-// entering each chunk of R rows is kept (the kernel re-runs the recurrence).
-static void build_betc(const QgGeom &g, int R, double aoc, const double *boc /* per spectral index */,
-                       double *boc_out /* ldw */, double *betc /* TH_NC*ldw */, int *rconv /* ldw */) {
+// Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477 (box) / 577-582 (cyclic), run once on the host.
+// The recurrence reaches a bitwise fixed point after a few rows for most spectral indices; per block of TH_KW indices
+// the pivots of the local rows before the block's slowest index is stationary are tabulated (rows of TH_KW doubles),
+// plus the stationary pivot per index.  Appends the tables of one layer (set of diagonals) to T.
+struct ThomasTabHost {
+  std::vector<double> binf, ptab;
+  std::vector<int> rcb, poff;
+};
+static void build_pivots(const QgGeom &g, double aoc, const double *boc /* per spectral index */, ThomasTabHost &T) {
   const int nr = g.jr1 - g.jr0 + 1;         // rows of this slab
   const int rg0 = g.jr0 + g.joff - 2;       // global interior-row index of the slab's first row
-  for (int k = 0; k < g.nk; ++k) {
-    boc_out[k] = boc[k];
-    double betinv = 1.0 / boc[k]; // global interior row 0
-    int gconv = rg0 + nr;         // first global row whose pivot equals its predecessor's (bitwise)
-    for (int rg = 0; rg < rg0 + nr; ++rg) {
-      if (rg > 0) {
-        double gam = aoc * betinv;
-        double nb = 1.0 / (boc[k] - aoc * gam);
-        if (nb == betinv && gconv == rg0 + nr) gconv = rg;
-        betinv = nb;
+  const int nblk = (g.nk + TH_KW - 1) / TH_KW;
+  const size_t b0 = T.binf.size();
+  T.binf.resize(b0 + g.ldw, 0.0);
+  std::vector<double> piv((size_t)TH_KW * nr);
+  for (int bx = 0; bx < nblk; ++bx) {
+    int rcb = 1; // at least one row, so that the kernel's clamped table read is always in bounds
+    std::fill(piv.begin(), piv.end(), 0.0);
+    for (int kk = 0; kk < TH_KW; ++kk) {
+      const int k = bx * TH_KW + kk;
+      if (k >= g.nk) continue;
+      double betinv = 1.0 / boc[k]; // global interior row 0
+      int gconv = rg0 + nr;         // first global row whose pivot equals its predecessor's (bitwise)
+      for (int rg = 0; rg < rg0 + nr; ++rg) {
+        if (rg > 0) {
+          double gam = aoc * betinv;
+          double nb = 1.0 / (boc[k] - aoc * gam);
+          if (nb == betinv && gconv == rg0 + nr) gconv = rg;
+          betinv = nb;
+        }
+        if (rg >= rg0) piv[(size_t)(rg - rg0) * TH_KW + kk] = betinv;
       }
-      // betinv is the pivot of global row rg; it enters the chunk that starts at local row rg+1-rg0
-      const int rl = rg + 1 - rg0;
-      if (rl >= 0 && rl % R == 0 && rl / R < TH_NC) betc[(size_t)(rl / R) * g.ldw + k] = betinv;
+      T.binf[b0 + k] = betinv; // the stationary value (or, if never stationary, unused: rcb = nr then)
+      int lc = gconv - rg0;
+      lc = lc < 0 ? 0 : (lc > nr ? nr : lc);
+      if (lc > rcb) rcb = lc;
     }
-    // a chunk starting at local row r0 >= gconv - rg0 sees only the stationary pivot (= its betc entry)
-    int lc = gconv - rg0;
-    rconv[k] = lc < 0 ? 0 : lc;
+    T.rcb.push_back(rcb);
+    T.poff.push_back((int)(T.ptab.size() / TH_KW));
+    T.ptab.insert(T.ptab.end(), piv.begin(), piv.begin() + (size_t)rcb * TH_KW);
   }
 }
 
-static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
+// (re)allocates the device tables as needed and uploads T (blocking copies: T may die at the caller's scope exit)
+static int upload_pivots(qgcm_hip_ctx *c, QgThomasTab &D, const ThomasTabHost &T) {
+  auto fit = [&](void **p, size_t &cap, size_t n, size_t el) -> int {
+    if (n <= cap && *p) return 0;
+    if (*p) HIPCHECK(hipFree(*p));
+    *p = nullptr;
+    HIPCHECK(hipMalloc(p, n * el));
+    cap = n;
+    return 0;
+  };
+  HIPCHECK(hipStreamSynchronize(c->stream)); // no launch may still be reading the old tables
+  if (fit((void **)&D.binf, D.binf_n, T.binf.size(), sizeof(double))) return 1;
+  if (fit((void **)&D.ptab, D.ptab_n, T.ptab.size(), sizeof(double))) return 1;
+  if (fit((void **)&D.rcb, D.rcb_n, T.rcb.size(), sizeof(int))) return 1;
+  if (fit((void **)&D.poff, D.poff_n, T.poff.size(), sizeof(int))) return 1;
+  HIPCHECK(hipMemcpy(D.binf, T.binf.data(), T.binf.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(D.ptab, T.ptab.data(), T.ptab.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(D.rcb, T.rcb.data(), T.rcb.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(D.poff, T.poff.data(), T.poff.size() * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, int nlayers, int phase,
                          const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st,
                          bool cyc_part_a = false);
 static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q);
@@ -351,16 +393,13 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   c->thR = thomas_rows_per_chunk(g.jr1 - g.jr0 + 1);
   if (c->thR < 0) QG_FAIL("qgcm_hip_set_grid: %d rows per slab exceed the single-segment Thomas kernel (<= 2048)", g.jr1 - g.jr0 + 1);
   {
-    std::vector<double> bocv((size_t)g.ldw * g.nl, 0.0), betc((size_t)g.ldw * TH_NC * g.nl, 0.0), boc(g.nk);
-    std::vector<int> rcv((size_t)g.ldw * g.nl, 0);
+    ThomasTabHost T;
+    std::vector<double> boc(g.nk);
     for (int m = 0; m < g.nl; ++m) {
       for (int k = 0; k < g.nk; ++k) boc[k] = bd2oc[k] - c->prm.rdm2oc[m];
-      build_betc(g, c->thR, c->prm.aoc, boc.data(), bocv.data() + (size_t)g.ldw * m, betc.data() + (size_t)g.ldw * TH_NC * m,
-                 rcv.data() + (size_t)g.ldw * m);
+      build_pivots(g, c->prm.aoc, boc.data(), T);
     }
-    HIPCHECK(hipMemcpy(c->rconv, rcv.data(), rcv.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(c->boc, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(c->betc, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (upload_pivots(c, c->tt, T)) return 1;
   }
   // FFT tables: complex length N = nxto (box DST-I of length nxto-1)
   const int N = g.nxt;
@@ -400,8 +439,8 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   c->grid_set = true;
   // slab summary constants (gain, backward image and column sums of the unit responses), once
-  if (launch_thomas(c, c->wrk, c->boc, c->betc, g.nl, 4, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
-  if (launch_thomas(c, c->wrk, c->boc, c->betc, g.nl, 5, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  if (launch_thomas(c, c->wrk, c->tt, g.nl, 4, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  if (launch_thomas(c, c->wrk, c->tt, g.nl, 5, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   {
     // weights of the spectral area integral (k_thomas.h): sum_{i=1}^{n-1} 2 sin(k i pi/n) = 2 cot(k pi/2n), k odd
     std::vector<double> wc((size_t)g.ldw, 0.0);
@@ -753,7 +792,7 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   return 0;
 }
 
-static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const double *betc, int nlayers, int phase,
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, int nlayers, int phase,
                          const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st,
                          bool cyc_part_a) {
   if (!st) st = c->stream;
@@ -768,9 +807,9 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const double *boc, const 
     QG_FAIL("qgcm_hip_thomas_phase: the set-up constants of the %d slabs have not been exchanged (qgcm_hip_set_thomas_consts)", nranks);
   P.ksum = c->ksum;
   P.wrk = wrk;
-  P.boc = boc;
-  P.betc = betc;
-  P.rconv = (boc == c->boc_tmp) ? c->rconv_tmp : c->rconv;
+  if (!tab.binf) QG_FAIL("k_thomas: the pivot tables have not been built (qgcm_hip_set_grid)");
+  P.binf = tab.binf; P.ptab = tab.ptab; P.rcb = tab.rcb; P.poff = tab.poff;
+  P.nblk = (g.nk + TH_KW - 1) / TH_KW;
   P.aoc = c->prm.aoc;
   P.ftnorm = g.cyc ? 1.0 / g.nxt : 0.5 / g.nxt; // src/ocisubs.F:440, 547
   P.nlayers = nlayers;
@@ -1095,13 +1134,13 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
     // cyclic / atmosphere, nxto = 64*M: inside qgcm_hip_steps part A of the constraint algebra rides in the Thomas
     // launch and part B in the fused inverse-transform kernel (3 launches after k_tend instead of 5)
     const bool fc = in_step && fuse_bdy && !c->no_fused_constr;
-    if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, fc)) return 1;
+    if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, fc)) return 1;
     if (!fc && launch_constr(c)) return 1;
     if (launch_rfft_unpack(c, fuse_bdy, fc)) return 1;
     c->ip ^= 1;
     return 0;
   }
-  if (launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   const bool fused_constr = in_step && fuse_bdy && can_fuse_dst_unpack(c) && !c->no_fused_constr;
   // area (and, cyclic, line) integrals are a by-product of the y sweeps: the constraints precede the inverse transform
   if (!fused_constr && launch_constr(c)) return 1;
@@ -1678,19 +1717,17 @@ extern "C" int qgcm_hip_helmholtz(qgcm_hip_handle c, double *wrk, const double *
   if (!c->whole) QG_FAIL("qgcm_hip_helmholtz: only for a handle that owns the whole domain");
   const QgGeom &g = c->g;
   // pivots for this boc (box: boc(i-1) multiplies sine wavenumber i-1, src/ocisubs.F:470-478)
-  std::vector<double> bocv((size_t)g.ldw, 0.0), betc((size_t)g.ldw * TH_NC, 0.0);
-  std::vector<int> rcv((size_t)g.ldw, 0);
-  build_betc(g, c->thR, c->prm.aoc, boc, bocv.data(), betc.data(), rcv.data());
-  HIPCHECK(hipMemcpyAsync(c->rconv_tmp, rcv.data(), rcv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(c->boc_tmp, bocv.data(), bocv.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipMemcpyAsync(c->betc_tmp, betc.data(), betc.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHECK(hipStreamSynchronize(c->stream)); // the staging vectors die at scope exit
+  {
+    ThomasTabHost T;
+    build_pivots(g, c->prm.aoc, boc, T);
+    if (upload_pivots(c, c->tt_tmp, T)) return 1;
+  }
   // box: interior columns i=2..nx-1 of every row -> wrk(c = i-2, j); cyclic: columns 1..nxto -> wrk(c = i-1, j)
   const int coff = g.cyc ? 0 : 1;
   HIPCHECK(hipMemcpy2DAsync(c->wrk, (size_t)g.ldw * 8, wrk + coff, (size_t)g.nx * 8, (size_t)g.nk * 8, (size_t)g.ny,
                             hipMemcpyHostToDevice, c->stream));
   if (launch_dst(c, c->wrk, 1, false)) return 1;
-  if (launch_thomas(c, c->wrk, c->boc_tmp, c->betc_tmp, 1, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  if (launch_thomas(c, c->wrk, c->tt_tmp, 1, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   if (launch_dst(c, c->wrk, 1, true)) return 1;
   HIPCHECK(hipMemcpy2DAsync(wrk + coff, (size_t)g.nx * 8, c->wrk, (size_t)g.ldw * 8, (size_t)g.nk * 8, (size_t)g.ny,
                             hipMemcpyDeviceToHost, c->stream));
@@ -1803,7 +1840,7 @@ extern "C" int qgcm_hip_thomas_phase(qgcm_hip_handle c, int phase, const double 
   if (phase < 1 || phase > 2) QG_FAIL("qgcm_hip_thomas_phase: phase must be 1 or 2");
   if ((phase == 1 && !send_dev) || (phase == 2 && !gath_dev)) QG_FAIL("qgcm_hip_thomas_phase: missing buffer");
   if (nranks > 64) QG_FAIL("qgcm_hip_thomas_phase: at most 64 slabs");
-  return launch_thomas(c, c->wrk, c->boc, c->betc, c->g.nl, phase, gath_dev, send_dev, rank, nranks, 0, nullptr);
+  return launch_thomas(c, c->wrk, c->tt, c->g.nl, phase, gath_dev, send_dev, rank, nranks, 0, nullptr);
 }
 
 extern "C" int qgcm_hip_constr(qgcm_hip_handle c) {
