@@ -133,14 +133,35 @@ __device__ __forceinline__ void dftM<15>(cplx *a) {
   for (int k = 0; k < 15; ++k) a[k] = t[k];
 }
 
+// Inclusive sum scan over the 64 lanes of a wave for two values at once, by DPP moves (VALU only; the shuffle form
+// costs two ds_bpermute per value and step on the LDS pipe, which is what bounds these kernels).  Within each row of 16
+// lanes: shifts by 1, 2, 4, 8 (lanes without a source add 0); then lane 15 of rows 0 / 2 is added to rows 1 / 3, and
+// lane 31 to rows 2 and 3.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double d64_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void d64_wave_scan2(double &a, double &b) {
+  a += d64_dpp<0x111, 0xf>(a); b += d64_dpp<0x111, 0xf>(b); // row_shr:1
+  a += d64_dpp<0x112, 0xf>(a); b += d64_dpp<0x112, 0xf>(b); // row_shr:2
+  a += d64_dpp<0x114, 0xf>(a); b += d64_dpp<0x114, 0xf>(b); // row_shr:4
+  a += d64_dpp<0x118, 0xf>(a); b += d64_dpp<0x118, 0xf>(b); // row_shr:8
+  a += d64_dpp<0x142, 0xa>(a); b += d64_dpp<0x142, 0xa>(b); // row_bcast:15 into rows 1, 3
+  a += d64_dpp<0x143, 0xc>(a); b += d64_dpp<0x143, 0xc>(b); // row_bcast:31 into rows 2, 3
+}
+
 // The transform of one row pair by one wave: reads rowa/rowb (global), leaves the two output rows
 // in the wave's LDS buffer F viewed as doubles: row a at raw[pidx(i)], row b at raw[NP + pidx(i)],
 // i = 0..N-2, pidx(i) = i + (i >> 4), NP = N + N/16.  rsa / rsb = sums of the output rows.
+// Split in two so that a caller can issue its own prefetches BETWEEN the halves: the front half (row loads,
+// pre-twiddle, M-point DFTs) peaks at ~230 VGPRs, all dead when it returns.
 template <int M>
-__device__ __forceinline__ void dst64_core(const QgDstParams &P, const double *rowa, const double *rowb, bool has_b,
-                                           cplx *F, cplx *W64, int lane, double &rsa, double &rsb) {
+__device__ __forceinline__ void dst64_front(const QgDstParams &P, const double *rowa, const double *rowb, bool has_b,
+                                            cplx *F, cplx *W64, int lane) {
   constexpr int N = 64 * M, n = N - 1, NS2 = n / 2; // n odd: NS2 = N/2 - 1 = K
-  double *raw = reinterpret_cast<double *>(F); // rows a, b: raw[0..N-1], raw[N..2N-1]
 
   // Everything this lane will need from global tables is requested up front so
   // that it arrives together with the rows: W_N^(lane*k1), the dsint sine
@@ -163,54 +184,53 @@ __device__ __forceinline__ void dst64_core(const QgDstParams &P, const double *r
     W64[lane] = {w.x, w.y};
   }
 
-  // ---- (0) rows -> LDS, 16-byte coalesced ---------------------------------
-  {
-    const double2 *ga = reinterpret_cast<const double2 *>(rowa);
-    const double2 *gb = reinterpret_cast<const double2 *>(rowb);
-    double2 *ra = reinterpret_cast<double2 *>(raw);
-    double2 *rb = reinterpret_cast<double2 *>(raw + N);
-#pragma unroll
-    for (int u = 0; u < (N / 2 + 63) / 64; ++u) {
-      int t = lane + 64 * u;
-      if (t < N / 2) {
-        ra[t] = ga[t];
-        rb[t] = has_b ? gb[t] : double2{0.0, 0.0};
-      }
-    }
-  }
-  wave_lds_sync();
-
-  // ---- (1) pre-twiddle (dsint.f:19-33) into registers: a[n1] = z[64*n1 + lane]
+  // ---- (1) pre-twiddle (dsint.f:19-33) into registers: a[n1] = z[64*n1 + lane].  The row elements come straight
+  // from global memory: z_j needs x(k), x(n+1-k) with k = min(j, N-j) - for the 64 lanes two contiguous 512-byte runs
+  // per row (one ascending, one descending).  Staging the rows in LDS first (round 1) cost 15 KB of LDS writes and
+  // 30 KB of LDS reads per row pair on the pipe that bounds this kernel.
   cplx a[M];
+  {
+    const double *rb = has_b ? rowb : rowa; // the odd last row has no partner: its loads are redirected and zeroed
+    const double bsc = has_b ? 1.0 : 0.0;
+    double xav[M], xac[M], xbv[M], xbc[M];
 #pragma unroll
-  for (int n1 = 0; n1 < M; ++n1) {
-    const int j = 64 * n1 + lane;
-    const int k = (j <= NS2) ? j : N - j;
-    cplx z;
-    if (j == 0) {
-      z = {0.0, 0.0};
-    } else if (j == NS2 + 1) {
-      z = {4.0 * raw[j - 1], 4.0 * raw[N + j - 1]};
-    } else {
-      double xa = raw[k - 1], xac = raw[n - k];
-      double xb = raw[N + k - 1], xbc = raw[N + n - k];
-      double sn = snv[n1];
-      double t1a = xa - xac, t2a = sn * (xa + xac);
-      double t1b = xb - xbc, t2b = sn * (xb + xbc);
+    for (int n1 = 0; n1 < M; ++n1) {
+      const int j = 64 * n1 + lane;
+      const int k = (j <= NS2) ? j : N - j;
+      const int i1 = k > 0 ? k - 1 : 0, i2 = k > 0 ? n - k : 0; // j = 0: z = 0, loads clamped
+      xav[n1] = rowa[i1];
+      xac[n1] = rowa[i2];
+      xbv[n1] = rb[i1];
+      xbc[n1] = rb[i2];
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < M; ++n1) {
+      const int j = 64 * n1 + lane;
+      const double va = xav[n1], ca = xac[n1], vb = bsc * xbv[n1], cb = bsc * xbc[n1];
+      const double sn = snv[n1];
+      const double t1a = va - ca, t2a = sn * (va + ca);
+      const double t1b = vb - cb, t2b = sn * (vb + cb);
+      cplx z;
       if (j <= NS2) z = {t1a + t2a, t1b + t2b};
       else z = {t2a - t1a, t2b - t1b};
+      if (j == NS2 + 1) z = {4.0 * va, 4.0 * vb}; // k = N - j = j: both loads hit x(j)
+      if (j == 0) z = {0.0, 0.0};
+      a[n1] = z;
     }
-    a[n1] = z;
   }
   dftM<M>(a);
-  wave_lds_sync(); // every lane has finished reading the raw rows
 #pragma unroll
   for (int k1 = 0; k1 < M; ++k1) {
     cplx v = (k1 == 0) ? a[0] : cmul(a[k1], tw1[k1]);
     F[k1 * D64_ROW + lane + (lane >> 3)] = v;
   }
   wave_lds_sync();
+}
 
+template <int M>
+__device__ __forceinline__ void dst64_back(cplx *F, const cplx *W64, int lane, double &rsa, double &rsb) {
+  constexpr int N = 64 * M, n = N - 1, NS2 = n / 2;
+  double *raw = reinterpret_cast<double *>(F); // output rows a, b (padded)
   // ---- (2a) radix-8 over a (n2 = 8a + b), twiddle W64^(b*c), in place -------
   constexpr int NBF = M * 8;
 #pragma unroll
@@ -277,16 +297,9 @@ __device__ __forceinline__ void dst64_core(const QgDstParams &P, const double *r
     }
   }
   const cplx z0 = F[0];
-  // inclusive wave scan of the per-lane partial sums
+  // inclusive wave scan of the per-lane partial sums (DPP moves: no LDS-pipe instructions)
   double inca = suma, incb = sumb;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    double va = __shfl_up(inca, off), vb = __shfl_up(incb, off);
-    if (lane >= off) {
-      inca += va;
-      incb += vb;
-    }
-  }
+  d64_wave_scan2(inca, incb);
   const double b1a = 0.5 * z0.x, b1b = 0.5 * z0.y;
   double runa = b1a + (inca - suma), runb = b1b + (incb - sumb);
   wave_lds_sync(); // all spectrum reads done: reuse the buffer for the output rows
@@ -319,6 +332,13 @@ __device__ __forceinline__ void dst64_core(const QgDstParams &P, const double *r
     }
   }
   wave_lds_sync();
+}
+
+template <int M>
+__device__ __forceinline__ void dst64_core(const QgDstParams &P, const double *rowa, const double *rowb, bool has_b,
+                                           cplx *F, cplx *W64, int lane, double &rsa, double &rsb) {
+  dst64_front<M>(P, rowa, rowb, has_b, F, W64, lane);
+  dst64_back<M>(F, W64, lane, rsa, rsb);
 }
 
 // grid: (ceil(npairs / 4), nlayers), block 64*D64_WAVES = independent waves
@@ -389,83 +409,21 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
 // ---------------------------------------------------------------------------
 template <int M, int NL, bool BDY, bool HALO, bool CONSTR>
 __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(const QgDstParams P, const QgUnpackParams U,
-                                                                                const QgBdyParams B, const QgConstrLite C) {
+                                                                                      const QgBdyParams B, const QgConstrLite C) {
   constexpr int N = 64 * M, NP = N + N / 16;
   __shared__ __align__(16) cplx Fsh[NL][M * D64_ROW];
   __shared__ __align__(16) cplx W64sh[NL][64];
   __shared__ double hc_sh[NL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = tid >> 6; // = mode
-  if (CONSTR && wv == NL) { // the constraint wave
-    double xin[NL], dpn[NL - 1], x[NL - 1];
-    constr_xin<NL>(C, lane, xin);
-#pragma unroll
-    for (int k = 0; k < NL - 1; ++k) dpn[k] = C.sc->dpioc[k];
-    constr_box_solve<NL>(C, xin, dpn, x);
-    if (lane == 0) {
-#pragma unroll
-      for (int m = 1; m < NL; ++m) hc_sh[m] = x[m - 1];
-      if (blockIdx.x == 0) {
-#pragma unroll
-        for (int m = 0; m < NL; ++m) C.sc->xinhom[m] = xin[m];
-#pragma unroll
-        for (int k = 0; k < NL - 1; ++k) C.sc->hclco[k] = x[k];
-      }
-    }
-    __syncthreads(); // the barrier the transforming waves reach after dst64_core
-    return;
-  }
+  const int wv = tid >> 6; // = mode (NL: the constraint wave)
   const int ldw = P.g.ldw;
   const int ja = P.g.jr0 + 2 * blockIdx.x;     // local rows ja, ja+1 (grid is exactly the pairs)
   const bool has_b = (ja + 1 <= P.g.jr1);
   const long fs = U.g.fstride;
-  // Work split of the combine step: the nx-2 interior columns go round-robin over the threads (NIT
-  // full sweeps, nx = N+1); the two wall columns are done by lane 0 of waves 0 (W) and 1 (E).
-  // Everything the combine step reads from global memory is requested BEFORE the transform.
-  constexpr int NX = N + 1, NT = 64 * NL, NIT = (NX - 2 + NT - 1) / NT;
-  double oc[2][NIT][NL - 1];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int gi = 2 + tid + it * NT;
-      const bool ok = gi <= NX - 1 && (r == 0 || has_b);
-      const long o = (long)(ja + r - 1) * U.g.ldx + (gi - 1);
-#pragma unroll
-      for (int m = 1; m < NL; ++m) oc[r][it][m - 1] = ok ? U.ochom[fs * (m - 1) + o] : 0.0;
-    }
-  const bool wallcol = (lane == 0 && wv < 2);
-  const int gw = (wv == 0) ? 1 : NX, gn = (wv == 0) ? 2 : NX - 1; // wall column and its inward neighbour
-  double ocw[2][NL - 1], ocn[2][NL - 1], byw[2], ddw[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const bool ok = wallcol && (r == 0 || has_b);
-    const long ow = (long)(ja + r - 1) * U.g.ldx + (gw - 1), on = (long)(ja + r - 1) * U.g.ldx + (gn - 1);
-#pragma unroll
-    for (int m = 1; m < NL; ++m) {
-      ocw[r][m - 1] = ok ? U.ochom[fs * (m - 1) + ow] : 0.0;
-      ocn[r][m - 1] = ok ? U.ochom[fs * (m - 1) + on] : 0.0;
-    }
-    byw[r] = (BDY && ok) ? B.beta * B.yporel[ja + r - 1] : 0.0;
-    ddw[r] = (BDY && ok) ? B.ddynoc[ow] : 0.0;
-  }
-  double hc[NL];
-  if (!CONSTR) {
-#pragma unroll
-    for (int m = 1; m < NL; ++m) hc[m] = U.sc->hclco[m - 1];
-  }
-  {
-    const double *rowa = P.wrk + P.g.wstride * wv + (long)(ja - 1) * ldw;
-    double rsa, rsb;
-    dst64_core<M>(P, rowa, rowa + ldw, has_b, Fsh[wv], W64sh[wv], lane, rsa, rsb);
-  }
-  __syncthreads();
-  if (CONSTR) {
-#pragma unroll
-    for (int m = 1; m < NL; ++m) hc[m] = hc_sh[m];
-  }
   const int nx = U.g.nx, nyg = U.g.nyg, joff = U.g.joff;
+  constexpr int NX = N + 1;
+  double hc[NL];
   // y-slab halo messages (k_halo_pack's layout: [k][3 rows][ldx] of p, then [k][ldx] of q): the first / last three
   // owned rows go to the lower / upper neighbour straight from here (no separate pack launch)
   const int jlo = U.g.jlo, jhi = U.g.jhi, ldxm = U.g.ldx;
@@ -517,24 +475,110 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       msg_q(gi, gj, k, q);
     }
   };
-  // wall columns (W by wave 0, E by wave 1)
-  if (wallcol) {
+  // The two wall columns (W: side 0, E: side 1) of the row pair: one thread per side.  Everything they read from
+  // global memory is requested BEFORE the transform (wall_prefetch), used after it (wall_columns).
+  struct WallPre {
+    double ocw[2][NL - 1], ocn[2][NL - 1], byw[2], ddw[2];
+  };
+  auto wall_prefetch = [&](bool mine, int side, WallPre &w) {
+    const int gw = (side == 0) ? 1 : NX, gn = (side == 0) ? 2 : NX - 1; // wall column and its inward neighbour
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const bool ok = mine && (r == 0 || has_b);
+      const long ow = (long)(ja + r - 1) * U.g.ldx + (gw - 1), on = (long)(ja + r - 1) * U.g.ldx + (gn - 1);
+#pragma unroll
+      for (int m = 1; m < NL; ++m) {
+        w.ocw[r][m - 1] = ok ? U.ochom[fs * (m - 1) + ow] : 0.0;
+        w.ocn[r][m - 1] = ok ? U.ochom[fs * (m - 1) + on] : 0.0;
+      }
+      w.byw[r] = (BDY && ok) ? B.beta * B.yporel[ja + r - 1] : 0.0;
+      w.ddw[r] = (BDY && ok) ? B.ddynoc[ow] : 0.0;
+    }
+  };
+  auto wall_columns = [&](int side, const WallPre &w) {
+    const int gw = (side == 0) ? 1 : NX, gn = (side == 0) ? 2 : NX - 1;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (r == 1 && !has_b) break;
       const int gj = ja + r;
       const long o = (long)(gj - 1) * U.g.ldx + (gw - 1);
       double pl[NL];
-      point(gw, gj, r, ocw[r], pl);
+      point(gw, gj, r, w.ocw[r], pl);
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
       msg_p(gw, gj, pl);
       if (BDY) {
         double pin[NL];
-        point(gn, gj, r, ocn[r], pin);
-        bdy_q(o, pl, pin, byw[r], ddw[r], gw, gj);
+        point(gn, gj, r, w.ocn[r], pin);
+        bdy_q(o, pl, pin, w.byw[r], w.ddw[r], gw, gj);
       }
     }
+  };
+
+  if (CONSTR && wv == NL) {
+    // ---- the constraint wave: solve, hand hclco over through LDS, then (after the transform) the two wall columns -
+    // a separate code path, so that the prefetched wall values do not occupy registers of the transforming waves
+    WallPre w;
+    wall_prefetch(lane < 2, lane, w);
+    double xin[NL], dpn[NL - 1], x[NL - 1];
+    constr_xin<NL>(C, lane, xin);
+#pragma unroll
+    for (int k = 0; k < NL - 1; ++k) dpn[k] = C.sc->dpioc[k];
+    constr_box_solve<NL>(C, xin, dpn, x);
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 1; m < NL; ++m) hc_sh[m] = x[m - 1];
+      if (blockIdx.x == 0) {
+#pragma unroll
+        for (int m = 0; m < NL; ++m) C.sc->xinhom[m] = xin[m];
+#pragma unroll
+        for (int k = 0; k < NL - 1; ++k) C.sc->hclco[k] = x[k];
+      }
+    }
+    __syncthreads(); // the barrier the transforming waves reach after the transform
+#pragma unroll
+    for (int m = 1; m < NL; ++m) hc[m] = x[m - 1];
+    if (lane < 2) wall_columns(lane, w);
+    return;
+  }
+  // Work split of the combine step: the nx-2 interior columns go round-robin over the threads (NIT
+  // full sweeps, nx = N+1); the two wall columns are done by the constraint wave, or without one by thread 0 of the
+  // waves of modes 0 (W) and 1 (E).
+  // Everything the combine step reads from global memory is requested before the back half of the transform - after
+  // the front half, whose row loads need the registers (one wave per mode), so that the kernel keeps two waves per SIMD.
+  constexpr int NT = 64 * NL, NIT = (NX - 2 + NT - 1) / NT;
+  const double *rowa = P.wrk + P.g.wstride * wv + (long)(ja - 1) * ldw;
+  dst64_front<M>(P, rowa, rowa + ldw, has_b, Fsh[wv], W64sh[wv], lane);
+  asm volatile("" ::: "memory"); // keep the prefetch below the front half
+  double oc[2][NIT][NL - 1];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int gi = 2 + tid + it * NT;
+      const bool ok = gi <= NX - 1 && (r == 0 || has_b);
+      const long o = (long)(ja + r - 1) * U.g.ldx + (gi - 1);
+#pragma unroll
+      for (int m = 1; m < NL; ++m) oc[r][it][m - 1] = ok ? U.ochom[fs * (m - 1) + o] : 0.0;
+    }
+  const bool wallcol = !CONSTR && (lane == 0 && wv < 2);
+  WallPre wpre;
+  if (!CONSTR) wall_prefetch(wallcol, wv, wpre);
+  if (!CONSTR) {
+#pragma unroll
+    for (int m = 1; m < NL; ++m) hc[m] = U.sc->hclco[m - 1];
+  }
+  {
+    double rsa, rsb;
+    dst64_back<M>(Fsh[wv], W64sh[wv], lane, rsa, rsb);
+  }
+  __syncthreads();
+  if (CONSTR) {
+#pragma unroll
+    for (int m = 1; m < NL; ++m) hc[m] = hc_sh[m];
+  }
+  if (!CONSTR) {
+    if (wallcol) wall_columns(wv, wpre);
   }
   // interior columns
 #pragma unroll
