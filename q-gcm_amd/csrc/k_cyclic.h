@@ -44,12 +44,19 @@ __device__ __forceinline__ void cyc_bsums_block(const QgCycSumParams &P, int bid
   __shared__ double redw[5][4];
   const int tid = threadIdx.x;
   const int slice = bidx % BSUM_NB, north = (bidx / BSUM_NB) & 1, k = bidx / (2 * BSUM_NB);
-  const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt, ldx = P.g.ldx;
+  const int nx = P.g.nx, nxt = P.g.nxt, ldx = P.g.ldx;
   const long fs = P.g.fstride;
   const double *pom = P.pom + fs * k, *p = P.po + fs * k, *q = P.qo + fs * k;
   const double bcf = P.bcfaco, dxom2 = P.dxom2;
+  // y-slabs: the sums belong to the rank that owns the zonal boundary (global row 1 / nyg); the other ranks publish
+  // zeros (the consumers read rank 0's southern and the last rank's northern sums)
+  const bool own = north ? (P.g.jhi + P.g.joff == P.g.nyg) : (P.g.jlo + P.g.joff == 1);
+  if (!own) {
+    if (tid < 5) P.part[(long)bidx * 5 + tid] = 0.0;
+    return;
+  }
   // rows counted from the boundary inwards: r = 0 boundary row, 1, 2, 3
-  auto row = [&](int r) { return north ? (ny - 1 - r) : r; }; // 0-based local row
+  auto row = [&](int r) { return north ? (P.g.jhi - 1 - r) : (P.g.jlo - 1 + r); }; // 0-based local row
   auto PM = [&](int i, int r) { return pom[(long)row(r) * ldx + (cyc_col(i, nxt) - 1)]; };
   // Del^2 of pom on rows r = 0 (boundary, mixed BC), 1, 2 (interior 5-point, cyclic in x)
   auto D2 = [&](int i, int r) {
@@ -99,7 +106,10 @@ __device__ __forceinline__ void cyc_bsums_block(const QgCycSumParams &P, int bid
 // ---------------------------------------------------------------------------
 struct QgCycConstrParams {
   QgGeom g;
-  const double *bpart; // partial boundary line sums of k_cyc_bsums
+  const double *bpart; // partial boundary line sums of k_cyc_bsums (southern sums are read from here)
+  const double *bpart_n; // y-slabs: the northern sums (the last rank's part of the gathered step message); else = bpart
+  const double *ybnd;  // y-slabs: (2, nl) zonal-mean values of the solved modes at global rows 2 and nyg-1
+                       // (k_thomas PHASE 2, from the slab summaries); nullptr: read them from wrk
   double adfaco, delek_sgn; // 1/(12 dxo dyo f0); 0.5*sign(f0)*delek
   double ah2oc[QG_MAXL], ah4oc[QG_MAXL];
   const double *ksum, *wrk; // spectral column sums (k_thomas PHASE 0) and the solved spectral rows
@@ -120,7 +130,8 @@ __device__ __forceinline__ void constr_cyc_partA(const QgCycConstrParams &P, int
   double bs = 0.0;
   if (lane < 10 * NL) {
     const int ks = lane / 5, v = lane % 5;
-    for (int blk = 0; blk < BSUM_NB; ++blk) bs += P.bpart[((long)ks * BSUM_NB + blk) * 5 + v];
+    const double *src = (ks & 1) ? P.bpart_n : P.bpart;
+    for (int blk = 0; blk < BSUM_NB; ++blk) bs += src[((long)ks * BSUM_NB + blk) * 5 + v];
   }
   double bq[2 * NL][5];
 #pragma unroll
@@ -220,8 +231,8 @@ __device__ __forceinline__ void constr_cyc_partB(const QgCycConstrParams &P, int
 #pragma unroll
   for (int m = 0; m < NL; ++m) {
     s[m] = xn * P.ksum[(long)m * P.g.ldw];
-    ys[m] = xn * P.wrk[P.g.wstride * m + (long)1 * P.g.ldw];
-    yn[m] = -(xn * P.wrk[P.g.wstride * m + (long)(ny - 2) * P.g.ldw]);
+    ys[m] = xn * (P.ybnd ? P.ybnd[2 * m] : P.wrk[P.g.wstride * m + (long)1 * P.g.ldw]);
+    yn[m] = -(xn * (P.ybnd ? P.ybnd[2 * m + 1] : P.wrk[P.g.wstride * m + (long)(ny - 2) * P.g.ldw]));
   }
   double xin[NL], clhss[NL], clhsn[NL];
 #pragma unroll
@@ -288,13 +299,14 @@ __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {
 template <int NL, bool BDY>
 __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, const QgBdyParams B) {
   const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt;
+  const int nyg = P.g.nyg, joff = P.g.joff;
   const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
-  const int gj = blockIdx.y + 1;
-  if (gi > nx || gj > ny) return;
+  const int gj = blockIdx.y + P.g.jlo; // owned rows only (the halo rows of a y-slab come with the exchange)
+  if (gi > nx || gj > P.g.jhi) return;
   const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
   const int ci = (gi > nxt) ? 0 : gi - 1; // column nx is column 1
   auto point = [&](int jrow, double *pl) {
-    const bool inner = (jrow >= 2 && jrow <= ny - 1);
+    const bool inner = (jrow + joff >= 2 && jrow + joff <= nyg - 1);
     double pm[NL];
     pm[0] = (inner ? P.wrk[(long)(jrow - 1) * P.g.ldw + ci] : 0.0) + P.sc->c3 * P.pbh[jrow - 1];
 #pragma unroll
@@ -315,9 +327,10 @@ __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, cons
   point(gj, pl);
 #pragma unroll
   for (int k = 0; k < NL; ++k) P.pnew[P.g.fstride * k + o] = pl[k];
-  if (BDY && (gj == 1 || gj == ny)) {
+  const int G = gj + joff;
+  if (BDY && (G == 1 || G == nyg)) {
     double pin[NL];
-    point(gj == 1 ? 2 : ny - 1, pin);
+    point(G == 1 ? gj + 1 : gj - 1, pin);
     const double by = B.beta * B.yporel[gj - 1];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, cons
       if (k == 0) ap = B.f0A[0] * pl[0] + B.f0A[NL] * pl[1];
       else if (k == NL - 1) ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k];
       else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
-      if (P.g.atm && k == NL - 1 && gj == 1) // southern value of the top layer: src/vorsubs.F:470 reads row 2
+      if (P.g.atm && k == NL - 1 && G == 1) // southern value of the top layer: src/vorsubs.F:470 reads row 2
         ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pin[k];
       double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
       if (k == (P.g.atm ? 0 : NL - 1)) q = q + B.ddynoc[o]; // topography: ocean bottom layer nlo, atmosphere layer 1

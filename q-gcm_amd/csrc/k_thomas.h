@@ -112,7 +112,6 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const bool kok = k < P.g.nk;
   const double a = P.aoc;
   const int r0 = c * R;
-  const long msg = (long)TH_MSG * P.g.nl * ldw;
   const long mk = TH_MSG * ((long)m * ldw + kq);
   const double ft = P.ftnorm;
 
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   if (PHASE == 2) {
     // lane s stands for rank s (at most 64 slabs); wave wv works on wavenumber kq
     const bool act = lane < P.nranks && kq < P.g.nk;
-    const double *gs = P.gath + (long)lane * msg + mk;                                        // this step's summaries
+    const double *gs = P.gath + (long)lane * P.gath_stride + mk;                              // this step's summaries
     const double *gc = P.cgath + (long)lane * (TH_CST * P.g.nl * ldw) + TH_CST * ((long)m * ldw + kq); // set-up constants
     const double gCf = act ? gs[0] : 0.0, gCb = act ? gs[1] : 0.0, gS0 = act ? gs[2] : 0.0;
     const double gD = act ? gc[0] : 1.0, gE = act ? gc[1] : 0.0, gSP = act ? gc[2] : 0.0, gSQ = act ? gc[3] : 0.0;
@@ -183,9 +182,18 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     uin = __shfl(uin_s, P.rank);
     vin = __shfl(vin_s, P.rank);
     if (lane == 0 && kq < P.g.nk) P.ksum[(long)m * ldw + kq] = ft * term;
+    if (P.ybnd && kq == 0) {
+      // cyclic constraints: the zonal-mean solution next to the two zonal boundaries, on every rank, from the
+      // summaries: the value leaving rank 0 downwards is the solution at its first row (global row 2); the forward
+      // value leaving the last rank is the solution at its last row (global row nyg-1: nothing enters from above)
+      const double vfirst = __shfl(C2, 63), vlast = __shfl(Cs, P.nranks - 1);
+      if (lane == 0) {
+        P.ybnd[2 * m] = ft * vfirst;
+        P.ybnd[2 * m + 1] = ft * vlast;
+      }
+    }
   }
   // ---- forward: local affine maps (zero inflow); rows past the slab are the identity (PRED) or the zero map (PHASE 0)
-  // The chunk gain D = prod(-a*bet) is the same for both sweeps and is formed once (ascending rows).
   double C = 0.0, D = 1.0;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
@@ -217,14 +225,22 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     b[t] = a * b[t]; // the backward sweep only needs a*bet
   }
   // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
+  // (the chunk gain is formed again in descending order rather than reused from the forward sweep: the zonal-mean
+  // barotropic column of a channel is nearly singular, and with the reused product the coupled drop-in moved from
+  // 4e-15 to 3e-12 of the reference after one step)
   C = 0.0;
+  D = 1.0;
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
-    if (!PRED || r0 + t < nr) C = w[t] - b[t] * C;
+    if (!PRED || r0 + t < nr) {
+      C = w[t] - b[t] * C;
+      D = -b[t] * D;
+    }
   }
-  sC[c][kk] = C; // safe without a barrier: every wave read the forward maps in sC before the barrier above
+  sC[c][kk] = C; // safe without a barrier: every wave read the forward maps in sC / sD before the barrier above
+  sD[c][kk] = D;
   __syncthreads();
-  // sweep order is last chunk first: lane l stands for chunk 63-l (sD still holds the chunk gains)
+  // sweep order is last chunk first: lane l stands for chunk 63-l
   const int cr = 63 - lane;
   Cs = sC[cr][wv];
   Ds = sD[cr][wv];

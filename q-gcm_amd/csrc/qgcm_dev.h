@@ -93,6 +93,9 @@ struct QgThomasParams {
   double *slabDE;     // (4, ldw, nl): D, E, SP, SQ of this slab (PHASE 4/5 write, PHASE 1 reads)
   double *ksum;       // (ldw, nl): ftnorm * column sums of the solution per spectral index (see k_thomas.h)
   int rank, nranks;
+  long gath_stride;   // doubles between two ranks' step messages in gath (>= TH_MSG*nl*ldw: a cyclic ocean appends its
+                      // boundary line sums to the message)
+  double *ybnd;       // PHASE 2, cyclic: (2, nl) zonal-mean solution at global rows 2 and nyg-1 (see k_cyclic.h), or nullptr
   double *wrk;
   // Thomas pivots, tabulated by the host (build_pivots): per block of 16 spectral indices the pivots of the local rows
   // r < rcb (rcb = rows until the block's last index is bitwise stationary, >= 1), 16 doubles per row starting at row

@@ -58,6 +58,10 @@ struct qgcm_hip_ctx {
   int ip, iq; // p[ip] = po, p[ip^1] = pom ; q[iq] = qo, q[iq^1] = qom
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
   double *wrk, *rowsum;
+  double *ybnd = nullptr;                  // cyclic y-slabs: (2, nl) zonal-mean solution next to the zonal boundaries (k_thomas PHASE 2)
+  const double *slab_gath = nullptr;       // cyclic y-slabs: the gathered step messages of the last thomas phase 2
+  int slab_nranks = 1;
+  double *bpart_out = nullptr;             // where k_tend's extra workgroups put the boundary line sums (bpart, or the tail of the step message)
   QgThomasTab tt, tt_tmp;                  // Thomas pivot tables of the modal solves / of the last qgcm_hip_helmholtz
   double *slabDE;                          // y-slab summary constants (D, E, SP, SQ) per (mode, wavenumber)
   double *th_cgath = nullptr;              // all ranks' slabDE (rank-major), exchanged once (qgcm_hip_set_thomas_consts)
@@ -207,7 +211,7 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     g.jr0 = (g0 == 1) ? g.jlo + 1 : g.jlo;       // rows 2..nyg-1 of the global grid that this slab owns
     g.jr1 = (g1 == g.nyg) ? g.jhi - 1 : g.jhi;
     c->whole = (g0 == 1 && g1 == g.nyg);
-    if (prm->cyclic && !c->whole) QG_FAIL("qgcm_hip_create: y-slabs are implemented for the box ocean only");
+    if (prm->atmos && !c->whole) QG_FAIL("qgcm_hip_create: y-slabs are implemented for the oceans only");
   }
   g.nxt = g.nx - 1;
   g.nk = g.cyc ? g.nxt : g.nxt - 1;
@@ -227,6 +231,7 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   if (dalloc(&c->yporel, g.ny)) return 1;
   if (dalloc(&c->wrk, W * g.nl)) return 1;
   if (dalloc(&c->slabDE, (size_t)4 * g.ldw * g.nl)) return 1;
+  if (g.cyc && dalloc(&c->ybnd, 2 * QG_MAXL)) return 1;
   if (dalloc(&c->ksum, (size_t)g.ldw * g.nl)) return 1;
   if (dalloc(&c->wcot, (size_t)g.ldw)) return 1;
   if (dalloc(&c->bpart, (size_t)5 * BSUM_NB * 2 * g.nl)) return 1;
@@ -267,7 +272,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
       if (p) hipFree(p);
     delete m;
   }
-  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath, c->area_part, c->area_out};
+  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath, c->area_part, c->area_out, c->ybnd};
   for (double *p : vp)
     if (p) hipFree(p);
   double *omp[] = {c->oml.sst[0], c->oml.sst[1], c->oml.sst[2], c->oml.fnet, c->oml.wekto, c->oml.xfo,
@@ -300,6 +305,11 @@ static int thomas_rows_per_chunk(int nrows) {
   for (int r : {1, 2, 4, 8, 10, 12, 16, 20, 24, 32}) // rows per thread; 10 / 20: the 600- and 1200-row slabs of NAtl 1 km
     if (need <= r) return r;
   return -1;
+}
+
+// per-step message of one slab: the summaries of the two y sweeps; a cyclic ocean appends its boundary line sums
+static inline size_t slab_msg_len(const QgGeom &g) {
+  return (size_t)TH_MSG * g.nl * g.ldw + (g.cyc ? (size_t)5 * BSUM_NB * 2 * g.nl : 0);
 }
 
 // Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477 (box) / 577-582 (cyclic), run once on the host.
@@ -724,7 +734,7 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false) {
   if (g.cyc) {
     S.g = g;
     S.pom = P.pom; S.po = P.po; S.qo = P.qo;
-    S.part = c->bpart;
+    S.part = c->bpart_out ? c->bpart_out : c->bpart;
     S.bcfaco = P.bcfaco; S.dxom2 = P.dxom2; S.adfaco = P.adfaco; S.fnot = pr.fnot;
     S.dxo = pr.dxo; S.dyo = pr.dyo;
   }
@@ -801,6 +811,14 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
+  P.gath_stride = (long)slab_msg_len(g);
+  if (phase == 2 && g.cyc) {
+    P.ybnd = c->ybnd;
+    c->slab_gath = gath;
+    c->slab_nranks = nranks;
+  } else if (phase == 0) {
+    c->slab_gath = nullptr; // whole-column solve: the constraint algebra reads bpart and wrk
+  }
   P.slabDE = c->slabDE;
   P.cgath = (nranks == 1) ? c->slabDE : c->th_cgath; // a lone slab is its own rank 0
   if (phase == 2 && nranks > 1 && (!c->th_cgath || c->th_cgath_ranks != nranks))
@@ -887,7 +905,15 @@ static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q) {
   fill_constr_params(c, P);
   memset(&Q, 0, sizeof(Q));
   Q.g = g; Q.ksum = c->ksum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
-  Q.bpart = c->bpart;
+  Q.bpart = Q.bpart_n = c->bpart;
+  if (c->slab_gath) {
+    // y-slab stages: the boundary line sums travel at the end of the step messages (rank 0 owns the southern boundary,
+    // the last rank the northern one); the solution next to the boundaries comes from k_thomas PHASE 2
+    const size_t off = (size_t)TH_MSG * g.nl * g.ldw;
+    Q.bpart = c->slab_gath + off;
+    Q.bpart_n = c->slab_gath + (size_t)(c->slab_nranks - 1) * slab_msg_len(g) + off;
+    Q.ybnd = c->ybnd;
+  }
   Q.adfaco = 1.0 / (12.0 * pr2.dxo * pr2.dyo * pr2.fnot);
   Q.delek_sgn = 0.5 * (pr2.fnot >= 0.0 ? 1.0 : -1.0) * pr2.delek;
   for (int k = 0; k < g.nl; ++k) {
@@ -1807,7 +1833,7 @@ extern "C" int qgcm_hip_area_integrals(qgcm_hip_handle c, double *xin) {
   return qgcm_hip_get_inv_diag(c, xin, nullptr);
 }
 
-extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? TH_MSG * c->g.nl * c->g.ldw : 0; }
+extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? (int)slab_msg_len(c->g) : 0; }
 
 extern "C" int qgcm_hip_thomas_const_len(qgcm_hip_handle c) { return c ? TH_CST * c->g.nl * c->g.ldw : 0; }
 
@@ -1882,10 +1908,16 @@ extern "C" int qgcm_hip_halo_unpack(qgcm_hip_handle c, const double *from_lower_
 extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, double *b, double *cc, int rank, int nranks,
                                    int flags) {
   switch (stage) {
-    case 1:
-      if (qgcm_hip_qgostep(c)) return 1;
+    case 1: {
+      if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 1 needs the send buffer");
+      // cyclic: the boundary line sums of the tendency launch go straight into the tail of the step message
+      if (c && c->g.cyc) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
+      const int rc = qgcm_hip_qgostep(c);
+      if (c) c->bpart_out = nullptr;
+      if (rc) return 1;
       if (qgcm_hip_row_transform(c, 0)) return 1;
       return qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks);
+    }
     case 2:
       if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
       if (qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
@@ -1931,7 +1963,6 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   if (!id || nbytes < (int)sizeof(ncclUniqueId)) QG_FAIL("qgcm_hip_comm_init: need the %d-byte id of qgcm_hip_comm_unique_id", (int)sizeof(ncclUniqueId));
   if (nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) QG_FAIL("qgcm_hip_comm_init: bad rank %d of %d (at most 64 slabs)", rank, nranks);
   if (c->sc_comm) QG_FAIL("qgcm_hip_comm_init: this handle already has a communicator");
-  if (c->g.cyc) QG_FAIL("qgcm_hip_comm_init: y-slabs are implemented for the box ocean only");
   const QgGeom &g = c->g;
   // the slab must be the rank-th piece of the basin: first rank owns global row 1, last rank row nyg
   if ((rank == 0) != (g.joff + g.jlo == 1) || (rank == nranks - 1) != (g.joff + g.jhi == g.nyg))
@@ -1945,7 +1976,7 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   m->nranks = nranks;
   const char *hp = getenv("QGCM_HIP_HALO_P2P");
   m->halo_p2p = hp && atoi(hp) != 0;
-  m->th_len = (size_t)TH_MSG * g.nl * g.ldw;
+  m->th_len = slab_msg_len(g);
   m->halo_len = (size_t)4 * g.nl * g.ldx;
   c->sc_comm = m; // owned by the handle from here on (freed in qgcm_hip_destroy)
   ncclUniqueId u;

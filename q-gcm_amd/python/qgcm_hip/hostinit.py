@@ -252,6 +252,32 @@ def homsol_cyc(cfg, rdm2, bd2, yporel, helmholtz):
     return out
 
 
+def helmholtz_cyc_column(cfg, rhs, boc):
+    """hscyoc (src/ocisubs.F:520-618) for a right-hand side that does not depend on x - all homsol asks of the cyclic
+    solver (conhoms.F:376-543): only the zonal-mean coefficient of every row is non-zero, so the solve is ONE
+    tridiagonal system in y with the diagonal boc(1) (same recurrence as the reference's sweep; the row transforms
+    reduce to the identity up to the rounding of nxto*c/nxto).  Used where no whole-domain handle exists (y-slabs)."""
+    r = np.asarray(rhs, dtype=np.float64)
+    col = r[0, :] if r.ndim == 2 else r
+    ny = cfg.nypo
+    aoc = 1.0 / (cfg.dyo * cfg.dyo)
+    b = float(np.asarray(boc)[0])
+    nr = ny - 2
+    u = np.zeros(nr)
+    gam = np.zeros(nr)
+    betinv = 1.0 / b
+    u[0] = col[1] * betinv
+    for j in range(1, nr):
+        gam[j] = aoc * betinv
+        betinv = 1.0 / (b - aoc * gam[j])
+        u[j] = (col[1 + j] - aoc * u[j - 1]) * betinv
+    for j in range(nr - 2, -1, -1):
+        u[j] = u[j] - gam[j + 1] * u[j + 1]
+    out = np.zeros((cfg.nxpo, ny), order="F")
+    out[:, 1:-1] = u[None, :]
+    return out
+
+
 def helmholtz_box_host(cfg, rhs, boc):
     """Init-only host solve of the box Helmholtz problem (same algorithm as hsbxoc,
     src/ocisubs.F:415-512: row DST-I, Thomas along y per wavenumber, row DST-I) with

@@ -234,7 +234,14 @@ class HipSlab:
         dd = np.asfortranarray(consts["ddynoc"][:, sl])
         check(self.L.qgcm_hip_set_grid(self.h, _dp(yp), _dp(bd2), _dp(dd)))
         self.consts = consts
-        if "ochom" in consts:  # global homogeneous solutions given; else SlabOcean.homsol() computes them on the slabs
+        if cfg.cyclic:
+            # the homogeneous solutions of a channel depend on y only (conhoms.F:376-543): local slices + global scalars
+            hg = consts
+            args = [np.asfortranarray(hg["pch1oc"][sl, :]), np.asfortranarray(hg["pch2oc"][sl, :]),
+                    np.ascontiguousarray(hg["pbhoc"][sl]),
+                    *[np.ascontiguousarray(hg[k], dtype=np.float64) for k in ("aipcho", "hc1soc", "hc2soc", "hc1noc", "hc2noc")]]
+            check(self.L.qgcm_hip_set_homog_cyc(self.h, *[_dp(a) for a in args], float(hg["hbsioc"]), float(hg["aipbho"])))
+        elif "ochom" in consts:  # global homogeneous solutions given; else SlabOcean.homsol() computes them on the slabs
             self.set_homog(np.asfortranarray(consts["ochom"][:, sl, :]), consts["cdiffo"], consts["cdhoc"])
         self.sync_each_call = sync_each_call
         self.device = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
@@ -294,6 +301,12 @@ class HipSlab:
         w, e = np.asfortranarray(wekpo, dtype=np.float64), np.asfortranarray(entoc, dtype=np.float64)
         x = np.ascontiguousarray(xon, dtype=np.float64)
         check(self.L.qgcm_hip_set_forcing(self.h, _dp(w), _dp(e), _dp(x)))
+
+    def set_cyc_forcing(self, txisoc, txinoc, enisoc=None, eninoc=None):
+        nl = self.cfg.nlo
+        es = np.zeros(nl - 1) if enisoc is None else np.ascontiguousarray(enisoc, dtype=np.float64)
+        en = np.zeros(nl - 1) if eninoc is None else np.ascontiguousarray(eninoc, dtype=np.float64)
+        check(self.L.qgcm_hip_set_cyc_forcing(self.h, float(txisoc), float(txinoc), _dp(es), _dp(en)))
 
     def set_scalars(self, s):
         s = np.ascontiguousarray(s, dtype=np.float64)
@@ -508,6 +521,10 @@ def global_consts(cfg, helmholtz=None):
     aoc, bd2 = hostinit.bd2oc(cfg)
     c = dict(amatoc=A, rdm2oc=rdm2, ctl2moc=cl2m, ctm2loc=cm2l, aoc=aoc, bd2oc=bd2, yporel=cfg.yporel(),
              ddynoc=np.zeros((cfg.nxpo, cfg.nypo), order="F"))
-    if helmholtz is not None:
+    if cfg.cyclic:
+        # channel: the homogeneous solutions depend on y only - a tridiagonal solve per mode, no 2-D solver needed
+        solve = helmholtz if helmholtz is not None else (lambda rhs, boc: hostinit.helmholtz_cyc_column(cfg, rhs, boc))
+        c.update(hostinit.homsol_cyc(cfg, rdm2, bd2, c["yporel"], solve))
+    elif helmholtz is not None:
         c.update(hostinit.homsol_box(cfg, rdm2, cm2l, bd2, helmholtz))
     return c

@@ -35,16 +35,25 @@ def main():
     # the reference: all P slabs as virtual ranks in this process
     vs = [HipSlab(cfg, consts, g0, g1, r, P, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
     vo = SlabOcean(cfg, vs, LocalComm(P, after=torch.cuda.synchronize))
-    vh = vo.homsol()
+    cyc = bool(cfg.cyclic)  # channel: the homogeneous solutions (functions of y) came with global_consts
+    txis, txin = synth.tau_line_integrals(cfg, tx) if cyc else (0.0, 0.0)
+    vh = None if cyc else vo.homsol()
     vo.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
+    if cyc:
+        for v in vs:
+            v.set_cyc_forcing(txis, txin)
     # this process's own slab, exchanges through torch.distributed
     g0, g1 = parts[rank]
     slab = HipSlab(cfg, consts, g0, g1, rank, P, device=0)
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=(sys.argv[2] != "p2p")))
-    dh = so.homsol()
-    ok = np.array_equal(dh["aipohs"], vh["aipohs"]) and np.array_equal(slab.ochom_local, vs[rank].ochom_local)
+    ok = True
+    if not cyc:
+        dh = so.homsol()
+        ok = np.array_equal(dh["aipohs"], vh["aipohs"]) and np.array_equal(slab.ochom_local, vs[rank].ochom_local)
     so.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
+    if cyc:
+        slab.set_cyc_forcing(txis, txin)
     for nst in (1, 1, 28):  # crosses the averaging after step 26
         so.steps(nst)
         vo.steps(nst)

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("name,halo", [("box_small", "allgather"), ("box_small", "p2p"), ("box_med", "allgather")])
+@pytest.mark.parametrize("name,halo", [("box_small", "allgather"), ("box_small", "p2p"), ("box_med", "allgather"),
+                                       ("cyc_med", "allgather"), ("cyc_small", "p2p")])
 def test_three_processes_one_slab_each(name, halo):
     port = 29600 + (hash((name, halo)) % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",

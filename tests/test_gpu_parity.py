@@ -360,6 +360,74 @@ def test_y_slab_decomposition_on_one_gpu(name, nranks):
         o.close()
 
 
+@pytest.mark.parametrize("name,nranks", [("cyc_small", 1), ("cyc_small", 2), ("cyc_med", 3), ("cyc_960", 4)])
+def test_cyclic_y_slab_decomposition_on_one_gpu(name, nranks):
+    """Zonally cyclic ocean on y-slabs (virtual ranks on this one GPU): the boundary line sums of the momentum
+    constraints ride in the step message (rank 0 owns the southern, the last rank the northern boundary), the
+    zonal-mean solution next to the boundaries comes out of the composed slab summaries - no second exchange -
+    and every rank runs the constraint algebra redundantly.  Against the whole-domain model and the oracle."""
+    import torch
+    from qgcm_hip import OceanModel, hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset(name)
+    o = make_oracle(cfg)
+    m = OceanModel(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg)  # homogeneous solutions of the channel from the 1-D column solver
+        for k in ("pch1oc", "pch2oc"):
+            assert relerr(consts[k], m.homog[k]) < 1e-12, k
+        assert relerr(consts["aipcho"], m.homog["aipcho"]) < 1e-11
+        # hc2soc / hc1noc are the exponentially small far-boundary responses: compare on the scale of the four together
+        hscale = max(np.abs(m.homog[k]).max() for k in ("hc1soc", "hc2soc", "hc1noc", "hc2noc"))
+        for k in ("hc1soc", "hc2soc", "hc1noc", "hc2noc"):
+            assert np.abs(consts[k] - m.homog[k]).max() / hscale < 1e-11, k
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        pom = np.asfortranarray(0.99 * po)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        txis, txin = synth.tau_line_integrals(cfg, tx)
+        ent = np.asfortranarray(1e-7 * np.cos(np.arange(cfg.nxpo - 1) * 2 * np.pi / (cfg.nxpo - 1))[:, None] * np.ones(cfg.nypo)[None, :])
+        ent = np.asfortranarray(np.vstack([ent, ent[:1]]))  # periodic: column nxpo = column 1
+        xon = np.zeros(cfg.nlo - 1)
+        enis = np.full(cfg.nlo - 1, 3e-4)
+        enin = np.full(cfg.nlo - 1, -2e-4)
+        for mod in (m, o):
+            mod.set_p(po, pom)
+            mod.set_forcing(wek, ent, xon)
+            mod.set_cyc_forcing(txis, txin, enis, enin)
+        qo, qom = m.get_state()[2], m.get_state()[3]
+        scal = m.get_scalars()
+        parts = partition(cfg.nypo, nranks)
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
+        for sl in slabs:
+            sl.set_cyc_forcing(txis, txin, enis, enin)
+        so.steps(30, s0=1)
+        m.steps(30, s0=1)
+        o.steps(1, 30)
+        got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+        for g0, g1, fields in so.gather_local():
+            for dst, src in zip(got, fields):
+                dst[:, g0 - 1:g1, :] = src
+        for f, x, y, z in zip(FIELDS, got, m.get_state(), o.get_state()):
+            assert relerr(x, y) < 1e-10, (f, nranks, "vs whole-domain handle")
+            assert relerr(x, z) < 1e-10, (f, nranks, "vs oracle")
+        nl = cfg.nlo
+        scale = cfg.xlo * cfg.ylo * np.abs(po).max()
+        ss, sm = slabs[0].get_scalars(), m.get_scalars()
+        assert np.abs(ss[:2 * (nl - 1)] - sm[:2 * (nl - 1)]).max() / scale < 1e-12
+        assert relerr(ss[2 * (nl - 1):], sm[2 * (nl - 1):]) < 1e-9
+        for sl in slabs:
+            assert np.array_equal(sl.get_scalars(), slabs[0].get_scalars())
+    finally:
+        for sl in slabs:
+            sl.close()
+        m.close()
+        o.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json full size (NAtl 5 km, 961 x 961 x 3)
 # ---------------------------------------------------------------------------
@@ -501,17 +569,17 @@ def test_full_size_socn5_cyclic_vs_oracle():
         o.close()
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_library_issued_exchanges_one_rank(graph, monkeypatch):
+@pytest.mark.parametrize("name,graph", [("box_small", False), ("box_small", True), ("cyc_small", False), ("cyc_small", True)])
+def test_library_issued_exchanges_one_rank(name, graph, monkeypatch):
     """qgcm_hip_slab_steps: the distributed step with the RCCL exchanges issued by the library
     itself, on a real (one-rank) RCCL communicator -- all a one-GPU box can hold; eager and as
     50-step HIP graphs that contain the collectives.  Bitwise equal to the same slab kernels
-    driven stage by stage from Python (the path the virtual-rank tests pin to the oracle)."""
+    driven stage by stage from Python (the path the virtual-rank tests pin to the oracle).  Box and cyclic ocean."""
     import torch
     from qgcm_hip import hostinit, synth
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, rccl_unique_id
     monkeypatch.setenv("QGCM_HIP_SLAB_GRAPH", "1" if graph else "0")
-    cfg = preset("box_small")
+    cfg = preset(name)
     o = make_oracle(cfg)
     slabs = []
     try:
@@ -519,6 +587,7 @@ def test_library_issued_exchanges_one_rank(graph, monkeypatch):
         po = synth.gaussian_eddy(cfg, noise=1e-2)
         tx, ty = synth.wind_stress(cfg)
         _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        txis, txin = synth.tau_line_integrals(cfg, tx) if cfg.cyclic else (0.0, 0.0)
         zero2 = np.zeros((cfg.nxpo, cfg.nypo), order="F")
         xon = np.zeros(cfg.nlo - 1)
         qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
@@ -529,6 +598,8 @@ def test_library_issued_exchanges_one_rank(graph, monkeypatch):
             slabs.append(sl)
             so = SlabOcean(cfg, [sl], LocalComm(1, after=torch.cuda.synchronize))
             so.scatter_state(po, po, qo, qo, wek, zero2, xon, scal)
+            if cfg.cyclic:
+                sl.set_cyc_forcing(txis, txin)
             if native:
                 so.use_library_exchanges(rccl_unique_id())
             so.steps(57, s0=1)   # graph mode: one 50-step block + 7 eager steps
