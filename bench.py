@@ -212,7 +212,9 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
     slab = HipSlab(cfg, consts, g0, g1, rank, world, device=local_rank)
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=not halo_p2p))
-    so.homsol()  # homogeneous solutions by the distributed Helmholtz solve itself (no host-side solver)
+    if not cfg.cyclic:
+        so.homsol()  # homogeneous solutions by the distributed Helmholtz solve itself (no host-side solver)
+    # (channel: they are functions of y and came with global_consts - a tridiagonal solve per mode)
     driver = "torch.distributed (RCCL) between qgcm_hip_slab_stage calls"
     if use_library:
         so.use_library_exchanges(broadcast_unique_id(dist, slab.device))
@@ -220,6 +222,8 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
         driver = "library-issued RCCL (qgcm_hip_slab_steps)"
     driver += ", halo rows by %s" % ("send/recv" if halo_p2p else "all-gather")
     so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
+    if cfg.cyclic:
+        slab.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
     del po, qo, wek, consts
     t_setup = time.perf_counter() - t_setup
     so.steps(nwarm, s0=1)
@@ -436,6 +440,12 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                                                   "NAtl 1km ocean-only, 3 layers, y-slabs over %d GPUs" % world)
             except Exception as e:  # noqa: BLE001
                 extra["natl1km"] = {"error": repr(e)}
+        # (3) BASELINE configs[2]: Southern Ocean 5 km periodic channel (4609 x 577 x 3) cut into `world` slabs
+        try:
+            extra["socn5_cyclic_slabs"] = slab_secondary(preset("socn5"), world, rank, local_rank, barrier, lib_ok, p2p, 200, 40,
+                                                         "SOcn 5km cyclic channel, fixed basin over %d GPUs" % world)
+        except Exception as e:  # noqa: BLE001
+            extra["socn5_cyclic_slabs"] = {"error": repr(e)}
         dog2.cancel()
     if rank == 0:
         real_stdout.write(line(*best, library_exchanges=lib_status))
