@@ -14,8 +14,13 @@
 //                off => sst is bitwise the reference's), new sst into the spare buffer (the sst buffers
 //                rotate: new -> sst, sst -> sstm), raw entrainment xfo, per-workgroup partial sums
 //   k_oml_entoc  every workgroup re-reduces the partials in the same fixed order (no extra launch, same mean
-//                everywhere), entoc = average of (xfo - mean) onto the p points, partials of xintp / line sums
-//   k_oml_final  one workgroup: xon(1), enisoc(1), eninoc(1), monitors cfraoc / centoc
+//                everywhere), entoc = average of (xfo - mean) onto the p points, partials of xintp / line sums.
+//                One generation of workgroups (OML_ERR tile rows each): the re-reduction is a ~2 us prologue that
+//                every generation pays (round 1: 3.5 generations, 9.3 us for 15 MB of work)
+//   k_oml_final  one workgroup: xon(1), enisoc(1), eninoc(1), monitors cfraoc / centoc.  Inside qgcm_hip_steps
+//                this is not a launch: workgroup 0 of the tendency kernel that follows does it (oml_final_block),
+//                before it steps dpioc with the new xon (a device-wide completion counter instead would need
+//                device-scope fences - an L2 write-back per workgroup on this multi-XCD part: measured 84 us)
 // The reference's sums run over j then i (and thread-dependent under OpenMP); here the order is fixed but
 // different, so the mean entrainment agrees to rounding (tests: 1e-13 of max|xfo|), everything else bitwise.
 // Algorithmic traffic: read sstm, sst, po(1), tauxo, tauyo, fnetoc, wekto (7) + write sst, xfo (2) in the first
@@ -27,6 +32,7 @@
 #define OML_TY 4
 #define OML_NT (OML_TX * OML_TY)
 #define OML_RPT 4 // rows per thread in k_oml_step
+#define OML_ERR 1 // tile rows per workgroup in k_oml_entoc (4: one generation of fat workgroups - 17 us instead of 9)
 
 struct QgOmlParams {
   int nxt, nyt, nx, ny, cyc, sb, nb;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
   }
 }
 
-// grid: (ceil(nx/64), ceil(ny/16)), block 256 = 64 x 4, thread rows j0 + ty + 4 r
+// grid: (ceil(nx/64), ceil(ny/(16*OML_ERR))), block 256 = 64 x 4, thread rows j0 + ty + 4 r of OML_ERR tile rows
 __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
   __shared__ double redm[4], red[12];
   const int tid = threadIdx.x;
@@ -209,9 +215,10 @@ __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
   const int nx = P.nx, ny = P.ny, nxt = P.nxt, nyt = P.nyt;
   const long ldt = P.ldt;
   double t[3] = {0.0, 0.0, 0.0}; // xintp sum, S and N line sums
+  for (int rr = 0; rr < OML_ERR; ++rr)
 #pragma unroll
   for (int r = 0; r < OML_RPT; ++r) {
-    const int j = blockIdx.y * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + 1;
+    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + 1;
     if (i > nx || j > ny) continue;
 #define XF(ii, jj) (P.xfo[(long)((jj)-1) * ldt + ((ii)-1)] - xmean)
     double en;
@@ -247,9 +254,17 @@ __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
   }
 }
 
-__global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlParams P) {
-  __shared__ double red[20];
-  const int tid = threadIdx.x;
+// what the final reduction needs (also carried by the tendency kernel's parameters, see k_tend.h)
+struct QgOmlFinal {
+  const double *partA, *partB;
+  int nblkA, nblkB, cyc, on;
+  QgScalars *sc;
+  double *diag;
+  double ocnorm, dxo, dyo;
+};
+
+// one workgroup of OML_NT threads; red: 20 doubles of LDS
+__device__ __forceinline__ void oml_final_block(const QgOmlFinal &P, double *red, int tid) {
   double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int k = tid; k < P.nblkB; k += OML_NT) {
     a[0] += P.partB[k];
@@ -271,6 +286,11 @@ __global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlParams P) {
     P.diag[0] = t[3] * P.ocnorm;        // cfraoc, :207
     P.diag[1] = t[4] * P.dxo * P.dyo;   // centoc, :208
   }
+}
+
+__global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlFinal P) {
+  __shared__ double red[20];
+  oml_final_block(P, red, threadIdx.x);
 }
 
 // leapfrog averaging of the mixed-layer temperature, src/q-gcm.F:1345-1351

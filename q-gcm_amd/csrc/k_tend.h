@@ -31,6 +31,7 @@
 #include "qgcm_dev.h"
 #include "k_misc.h" // constr_dpi_update
 #include "k_cyclic.h" // cyc_bsums_block
+#include "k_oml.h" // oml_final_block
 
 #ifndef TEND_TX
 #define TEND_TX 16
@@ -164,7 +165,9 @@ template <int NL, bool CYC>
 #ifndef TEND_WAVES_PER_EU
 #define TEND_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P, const QgCycSumParams S) {
+__global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P, const QgCycSumParams S,
+                                                                     const QgOmlFinal F) {
+  static_assert(TEND_NT == OML_NT, "oml_final_block runs in workgroup 0 of this kernel");
   constexpr int TX = TEND_TX, TY = TEND_TY;
   constexpr int W3 = TX + 6, H3 = TY + 6; // pom tile, halo 3
   constexpr int W2 = TX + 4, H2 = TY + 4; // d2 tile, halo 2
@@ -192,6 +195,12 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   const int gx = T.gx, gy = T.gy;
   const int ntiles = gx * gy;
   const int per_xcd = (ntiles + 7) / 8;
+  if (F.on && blockIdx.x == 0) {
+    // mixed layer on, inside qgcm_hip_steps: the last reduction of `oml` (xon(1), enisoc(1) / eninoc(1), monitors) is
+    // done here instead of in a one-workgroup launch; xon must be final before dpioc is stepped below
+    __shared__ double redf[20];
+    oml_final_block(F, redf, tid);
+  }
   if (!CYC && P.upd_dpi && blockIdx.x == 0 && tid == 0) constr_dpi_update<NL>(P.sc, P.tdto, P.gpoc); // see QgTendParams
   if ((int)blockIdx.x >= 8 * per_xcd) {
     // cyclic / atmosphere: the boundary line sums for the momentum constraints (k_cyclic.h); box: the wall edges

@@ -699,7 +699,9 @@ static void drain_timers(qgcm_hip_ctx *c) {
   c->evkid.clear();
 }
 
-static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false) {
+static void fill_oml_final(qgcm_hip_ctx *c, QgOmlFinal &F, bool on);
+
+static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = false) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
   QgTendParams P;
@@ -738,12 +740,14 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false) {
     S.bcfaco = P.bcfaco; S.dxom2 = P.dxom2; S.adfaco = P.adfaco; S.fnot = pr.fnot;
     S.dxo = pr.dxo; S.dyo = pr.dyo;
   }
+  QgOmlFinal F;
+  fill_oml_final(c, F, oml_final && c->oml.on);
   const int nextra = g.cyc ? g.nl * 2 * BSUM_NB : T.nedge;
   dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
 #define QG_TEND(NLV)                                                                              \
-  if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true>), grid, dim3(TEND_NT), 0, c->stream, P, S);    \
-  else hipLaunchKernelGGL((k_tend<NLV, false>), grid, dim3(TEND_NT), 0, c->stream, P, S)
+  if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);    \
+  else hipLaunchKernelGGL((k_tend<NLV, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F)
   switch (g.nl) {
     case 2: QG_TEND(2); break;
     case 3: QG_TEND(3); break;
@@ -1245,7 +1249,7 @@ extern "C" int qgcm_hip_oml_init(qgcm_hip_handle c, const qgcm_hip_oml_params *p
     o.ldt = round_up(nxt, 16);
     const size_t nT = (size_t)o.ldt * nyt, nP = (size_t)g.ldx * g.ny;
     o.nblkA = ((nxt + OML_TX - 1) / OML_TX) * ((nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
-    o.nblkB = ((g.nx + OML_TX - 1) / OML_TX) * ((g.ny + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+    o.nblkB = ((g.nx + OML_TX - 1) / OML_TX) * ((g.ny + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
     struct { double **ptr; size_t n; } bufs[] = {{&o.sst[0], nT}, {&o.sst[1], nT}, {&o.sst[2], nT}, {&o.fnet, nT}, {&o.wekto, nT},
                                                  {&o.xfo, nT}, {&o.taux, nP}, {&o.tauy, nP}, {&o.partA, (size_t)3 * o.nblkA},
                                                  {&o.partB, (size_t)3 * o.nblkB}, {&o.diag, 2}};
@@ -1295,7 +1299,17 @@ extern "C" int qgcm_hip_oml_set_forcing(qgcm_hip_handle c, const double *fnetoc,
   return 0;
 }
 
-static int launch_oml(qgcm_hip_ctx *c) {
+static void fill_oml_final(qgcm_hip_ctx *c, QgOmlFinal &F, bool on) {
+  const auto &o = c->oml;
+  memset(&F, 0, sizeof(F));
+  F.partA = o.partA; F.partB = o.partB; F.nblkA = o.nblkA; F.nblkB = o.nblkB; F.cyc = c->g.cyc; F.on = on ? 1 : 0;
+  F.sc = c->sc; F.diag = o.diag;
+  F.ocnorm = 1.0 / ((double)c->g.nxt * (double)(c->g.ny - 1)); // src/parameters_data.F:88
+  F.dxo = c->prm.dxo; F.dyo = c->prm.dyo;
+}
+
+// with_final = false: the final reduction rides in workgroup 0 of the tendency launch that follows (one_step)
+static int launch_oml(qgcm_hip_ctx *c, bool with_final = true) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
   auto &o = c->oml;
@@ -1325,10 +1339,14 @@ static int launch_oml(qgcm_hip_ctx *c) {
   P.dxo = pr.dxo; P.dyo = pr.dyo;
   KTimer t(c, KN_OML);
   dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
-  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.ny + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.ny + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
   hipLaunchKernelGGL(k_oml_step, gA, dim3(OML_NT), 0, c->stream, P);
   hipLaunchKernelGGL(k_oml_entoc, gB, dim3(OML_NT), 0, c->stream, P);
-  hipLaunchKernelGGL(k_oml_final, dim3(1), dim3(OML_NT), 0, c->stream, P);
+  if (with_final) {
+    QgOmlFinal F;
+    fill_oml_final(c, F, true);
+    hipLaunchKernelGGL(k_oml_final, dim3(1), dim3(OML_NT), 0, c->stream, F);
+  }
   HIPCHECK(hipGetLastError());
   // rotation: sstm <- sst, sst <- new (src/omlsubs.F:125-126)
   o.ism = o.is;
@@ -1574,10 +1592,10 @@ extern "C" int qgcm_hip_prsamp(qgcm_hip_handle c, double *out) {
 }
 
 static int one_step(qgcm_hip_ctx *c, int s) {
-  if (c->oml.on && launch_oml(c)) return 1; // src/q-gcm.F:1232
+  if (c->oml.on && launch_oml(c, false)) return 1; // src/q-gcm.F:1232; its final reduction rides in launch_tend
   const bool fused_constr = !c->g.cyc && can_fuse_dst_unpack(c) && !c->no_fused_constr; // see ocinvq_impl
   if (check_ready(c, "qgcm_hip_steps")) return 1;
-  if (launch_tend(c, fused_constr)) return 1;
+  if (launch_tend(c, fused_constr, c->oml.on)) return 1;
   c->iq ^= 1; // as qgcm_hip_qgostep
   if (ocinvq_impl(c, true, true)) return 1; // ocqbdy fused into the unpack kernel
   if ((s - 1) % c->avg_period == 0) {
