@@ -28,6 +28,17 @@
 struct cplx {
   double x, y;
 };
+
+// Where the FFT part of the row kernels keeps element n of its input / element k of its spectrum in LDS.  The
+// Stockham stages below are autosort (natural order); the three-stage plans of k_fft3.h are padded and digit-reversed.
+struct FftPlanNatural {
+  static constexpr bool three_stage = false;
+  struct Tw {};
+  template <int NT>
+  static __device__ __forceinline__ Tw prefetch(const double2 *, int) { return Tw{}; }
+  static __device__ __forceinline__ int pos_in(int n) { return n; }
+  static __device__ __forceinline__ int pos_out(int k) { return k; }
+};
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -182,14 +193,16 @@ __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict_
 // grid: (ceil(nrows/2), nlayers);  rows j = jr0..jr1 (owned, interior to the global domain)
 // dynamic LDS: 2*N cplx + 2*NT doubles; NT = 128 threads for short rows, DST_NT_BIG for long ones (a long row
 // fills the LDS of a CU by itself, so the one resident workgroup must bring enough waves)
-template <bool ROWSUM, int NT = DST_NT>
+template <bool ROWSUM, int NT = DST_NT, class PLAN = FftPlanNatural>
 __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = P.N, n = N - 1;
-  const bool single = P.single != 0; // one LDS buffer, in-place stages (N even, see DST_SINGLE_*)
+  const bool single = PLAN::three_stage || P.single != 0; // one LDS buffer, in-place stages (N even, see DST_SINGLE_*)
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
   cplx *B = single ? A : A + N;
-  double *red = reinterpret_cast<double *>((single ? A : B) + N); // 2 * (NT / 64) doubles
+  double *red; // 2 * (NT / 64) doubles behind the buffer(s)
+  if constexpr (PLAN::three_stage) red = reinterpret_cast<double *>(A + PLAN::LDS_CPLX);
+  else red = reinterpret_cast<double *>((single ? A : B) + N);
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y + P.layer0;
@@ -197,6 +210,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   const bool has_b = (ja + 1 <= P.g.jr1);
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
   double *rowb = rowa + ldw;
+  typename PLAN::Tw tw3 = PLAN::template prefetch<NT>(P.twid, tid); // table values requested before the rows
 
   // ---- pre-twiddle (dsint.f:19-33): element a[k], k=1..n lives at index k-1
   const int ns2 = n / 2;
@@ -207,19 +221,21 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     double sn = P.sintab[k];
     double t1a = xa - xac, t2a = sn * (xa + xac);
     double t1b = xb - xbc, t2b = sn * (xb + xbc);
-    A[k] = {t1a + t2a, t1b + t2b};
-    A[N - k] = {t2a - t1a, t2b - t1b};
+    A[PLAN::pos_in(k)] = {t1a + t2a, t1b + t2b};
+    A[PLAN::pos_in(N - k)] = {t2a - t1a, t2b - t1b};
   }
   if ((n & 1) && tid == 0) {
     int kc = ns2 + 1;
     double xa = rowa[kc - 1], xb = has_b ? rowb[kc - 1] : 0.0;
-    A[kc] = {4.0 * xa, 4.0 * xb};
+    A[PLAN::pos_in(kc)] = {4.0 * xa, 4.0 * xb};
   }
   __syncthreads();
 
   // ---- complex FFT of length N, Stockham autosort ----------------------
   cplx *in = A, *out = B;
   int s = 1, len = N;
+  if constexpr (PLAN::three_stage) PLAN::template run<NT>(A, tw3, tid);
+  else
   for (int f = 0; f < P.nfac; ++f) {
     const int R = P.fac[f];
     const int mm = len / R;
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   const double b1a = 0.5 * Z[0].x, b1b = 0.5 * Z[0].y; // read before anything is staged over the spectrum
   double suma = 0.0, sumb = 0.0;
   for (int k = k0; k < k0 + chunk && k <= K; ++k) {
-    cplx z1 = Z[k], z2 = Z[N - k];
+    cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out(N - k)];
     suma += 0.5 * (z1.x + z2.x);
     sumb += 0.5 * (z1.y + z2.y);
   }
@@ -303,14 +319,14 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     rsb += b1b;
   }
   for (int k = k0; k < k0 + chunk && k <= K; ++k) {
-    cplx z1 = Z[k], z2 = Z[N - k];
+    cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out(N - k)];
     double rea = 0.5 * (z1.x + z2.x), ima = 0.5 * (z1.y - z2.y);
     double reb = 0.5 * (z1.y + z2.y), imb = -0.5 * (z1.x - z2.x);
     runa += rea;
     runb += reb;
     if (single) {
-      Z[k] = {-ima, runa};
-      Z[N - k] = {-imb, runb};
+      Z[PLAN::pos_out(k)] = {-ima, runa};
+      Z[PLAN::pos_out(N - k)] = {-imb, runb};
     } else {
       oa[2 * k - 1] = -ima; // b[2k]
       oa[2 * k] = runa;     // b[2k+1]
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   // n even: the last even output b[n] = -Im Y_{n/2} has no odd partner (never with one buffer: N is even there)
   if (!(n & 1) && tid == NT - 1) {
     int k = n / 2;
-    cplx z1 = Z[k], z2 = Z[N - k];
+    cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out(N - k)];
     double ima = 0.5 * (z1.y - z2.y), imb = -0.5 * (z1.x - z2.x);
     oa[n - 1] = -ima;
     rsa += -ima;
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   if (single) {
     for (int i = tid; i < n; i += NT) {
       const int k = (i + 1) >> 1;
-      const cplx za = Z[k], zb = Z[(N - k) % N];
+      const cplx za = Z[PLAN::pos_out(k)], zb = Z[PLAN::pos_out((N - k) % N)];
       const bool first = (i == 0) || (i & 1);
       rowa[i] = first ? za.x : za.y;
       if (has_b) rowb[i] = (i == 0) ? za.y : ((i & 1) ? zb.x : zb.y);
@@ -382,15 +398,16 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
 // grid: (ceil(nrows/2), nlayers); dynamic LDS: 2*N cplx + 2*DST_NT doubles
 // ---------------------------------------------------------------------------
 #define RFFT_NT 512
-template <bool INV>
-__global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
-  constexpr int NT = RFFT_NT;
+template <bool INV, class PLAN = FftPlanNatural, int NT = RFFT_NT>
+__global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int N = P.N, H = N / 2;
-  const bool single = P.single != 0;
+  const bool single = PLAN::three_stage || P.single != 0;
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
   cplx *B = single ? A : A + N;
-  double *red = reinterpret_cast<double *>((single ? A : B) + N); // 2 * (NT / 64) doubles
+  double *red; // 2 * (NT / 64) doubles behind the buffer(s)
+  if constexpr (PLAN::three_stage) red = reinterpret_cast<double *>(A + PLAN::LDS_CPLX);
+  else red = reinterpret_cast<double *>((single ? A : B) + N);
   const int tid = threadIdx.x;
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y + P.layer0;
@@ -398,9 +415,10 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
   const bool has_b = (ja + 1 <= P.g.jr1);
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
   double *rowb = rowa + ldw;
+  typename PLAN::Tw tw3 = PLAN::template prefetch<NT>(P.twid, tid); // table values requested before the rows
 
   if (!INV) {
-    for (int j = tid; j < N; j += NT) A[j] = {rowa[j], has_b ? rowb[j] : 0.0};
+    for (int j = tid; j < N; j += NT) A[PLAN::pos_in(j)] = {rowa[j], has_b ? rowb[j] : 0.0};
   } else {
     // half-complex rows -> conj(Z), Z_k = Xa_k + i Xb_k
     for (int k = tid; k <= H; k += NT) {
@@ -415,14 +433,16 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
         ar = rowa[2 * k - 1]; ai = rowa[2 * k];
         br = has_b ? rowb[2 * k - 1] : 0.0; bi = has_b ? rowb[2 * k] : 0.0;
       }
-      A[k] = {ar - bi, -(ai + br)};
-      if (k > 0 && k < H) A[N - k] = {ar + bi, -(br - ai)};
+      A[PLAN::pos_in(k)] = {ar - bi, -(ai + br)};
+      if (k > 0 && k < H) A[PLAN::pos_in(N - k)] = {ar + bi, -(br - ai)};
     }
   }
   __syncthreads();
 
   cplx *in = A, *out = B;
   int s = 1, len = N;
+  if constexpr (PLAN::three_stage) PLAN::template run<NT>(A, tw3, tid);
+  else
   for (int f = 0; f < P.nfac; ++f) {
     const int R = P.fac[f];
     const int mm = len / R;
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
   if (!INV) {
     // Xa_k = (Z_k + conj Z_{N-k})/2, Xb_k = (Z_k - conj Z_{N-k})/(2i)
     for (int k = tid; k <= H; k += NT) {
-      cplx z1 = Z[k], z2 = Z[(N - k) % N];
+      cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out((N - k) % N)];
       double ar = 0.5 * (z1.x + z2.x), ai = 0.5 * (z1.y - z2.y);
       double br = 0.5 * (z1.y + z2.y), bi = -0.5 * (z1.x - z2.x);
       if (k == 0) {
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(RFFT_NT) void k_rfft_cyc(const QgDstParams P) {
   } else {
     double rsa = 0.0, rsb = 0.0;
     for (int j = tid; j < N; j += NT) {
-      cplx z = Z[j];
+      cplx z = Z[PLAN::pos_out(j)];
       rowa[j] = z.x;
       rsa += z.x;
       if (has_b) {

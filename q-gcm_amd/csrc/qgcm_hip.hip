@@ -14,6 +14,10 @@
 #include "qgcm_dev.h"
 #include "k_tend.h"
 #include "k_dst.h"
+#include "k_fft3.h"
+// the row lengths with a three-stage plan: NAtl 1 km (4800), SOcn 5 km (4608), and two more for the tests
+#define FFT3_NT 256
+#define QG_FFT3_PLANS(X) X(1, 15, 16, 20) X(2, 16, 16, 18) X(3, 16, 16, 16) X(4, 12, 15, 16)
 #include "k_dst64.h"
 #include "k_thomas.h"
 #include "k_misc.h"
@@ -80,6 +84,8 @@ struct qgcm_hip_ctx {
   bool geom_set = false; // yporel / ddynoc are on the device (qgcm_hip_set_geometry or set_grid)
   bool whole; // the handle owns the whole domain (no y-slab neighbours)
   bool dst_single = false; // generic row kernels run single-buffer (in-place) stages
+  int fft3 = 0;            // long rows: three-stage register-radix plan of k_fft3.h (0 = none; index into QG_FFT3_PLANS)
+  size_t fft3_lds = 0;
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
@@ -447,6 +453,21 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false, DST_NT_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
   HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->dst_lds));
+  // long rows: the three-stage register-radix plans of k_fft3.h (QGCM_HIP_NO_FFT3=1: the Stockham plan, for A/B + tests)
+  c->fft3 = 0;
+  if (!getenv("QGCM_HIP_NO_FFT3")) {
+#define QG_FFT3_SETUP(ID, R1, R2, R3)                                                                                        \
+    if (N == R1 * R2 * R3) {                                                                                                 \
+      typedef Fft3Plan<R1, R2, R3> PL;                                                                                       \
+      c->fft3 = ID;                                                                                                          \
+      c->fft3_lds = (size_t)PL::LDS_CPLX * sizeof(cplx) + 2 * (FFT3_NT / 64) * sizeof(double);                               \
+      HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false, FFT3_NT, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
+      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false, PL, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
+      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true, PL, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
+    }
+    QG_FFT3_PLANS(QG_FFT3_SETUP)
+#undef QG_FFT3_SETUP
+  }
   c->grid_set = true;
   // slab summary constants (gain, backward image and column sums of the unit responses), once
   if (launch_thomas(c, c->wrk, c->tt, g.nl, 4, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
@@ -780,6 +801,20 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   dim3 grid(npairs, nlayers);
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
+  if (c->fft3 && !c->force_generic_dst) {
+    // long rows: three in-place register-radix stages (k_fft3.h)
+#define QG_FFT3_LAUNCH(ID, R1, R2, R3)                                                                                     \
+    if (c->fft3 == ID) {                                                                                                   \
+      typedef Fft3Plan<R1, R2, R3> PL;                                                                                     \
+      if (!g.cyc) hipLaunchKernelGGL((k_dst_box<false, FFT3_NT, PL>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);            \
+      else if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true, PL, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);      \
+      else hipLaunchKernelGGL((k_rfft_cyc<false, PL, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);                  \
+    }
+    QG_FFT3_PLANS(QG_FFT3_LAUNCH)
+#undef QG_FFT3_LAUNCH
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
   if (g.cyc) {
     // wave-per-row-pair fast path when nxto = 64*M (k_rfft64.h); the generic Stockham kernel otherwise
     const int M64 = (!c->force_generic_dst && c->fftN % 64 == 0) ? c->fftN / 64 : 0;

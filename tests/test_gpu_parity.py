@@ -257,7 +257,8 @@ def test_dynamic_topography_and_entrainment_fields():
             mod.close()
 
 
-@pytest.mark.parametrize("nxto,cyclic", [(3072, False), (4096, False), (5000, False), (2880, True), (4608, True), (2400, False)])
+@pytest.mark.parametrize("nxto,cyclic", [(3072, False), (4096, False), (5000, False), (2880, True), (4608, True), (2400, False), (4800, False),
+                                         (4096, True), (2880, False)])
 def test_long_row_transform_sizes(nxto, cyclic):
     """Generic row kernels on long rows: 2561 <= nxto <= 5104 runs the single-buffer in-place stages (two
     workgroups per CU), below that the two-buffer Stockham plan with 512 threads; radix mixes 8/4/2/3/5.
