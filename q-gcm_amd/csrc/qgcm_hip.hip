@@ -1115,7 +1115,8 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nu
   dim3 grid((nrows + 1) / 2);
   KTimer t(c, KN_DSTI);
 #define QG_DU(MV, NLV)                                                                                                  \
-  if (msg_lo || msg_hi) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C); \
+  if ((msg_lo || msg_hi) && constr) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
+  else if (msg_lo || msg_hi) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C); \
   else if (fuse_bdy && constr) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
   else if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C);  \
   else hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, false, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C)
@@ -1963,23 +1964,31 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
   switch (stage) {
     case 1: {
       if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 1 needs the send buffer");
+      if (check_ready(c, "qgcm_hip_slab_stage")) return 1;
       // cyclic: the boundary line sums of the tendency launch go straight into the tail of the step message
-      if (c && c->g.cyc) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
-      const int rc = qgcm_hip_qgostep(c);
-      if (c) c->bpart_out = nullptr;
+      if (c->g.cyc) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
+      // box fast path: as in qgcm_hip_steps the leapfrog of dpioc is done by the tendency launch and the constraint
+      // solve by the extra wave of the fused inverse-transform kernel of stage 2 (no k_constr_box launch)
+      if (!c->homog_set) QG_FAIL("qgcm_hip_slab_stage: homogeneous solutions not set");
+      const bool fused_constr = can_fuse_dst_unpack(c) && !c->no_fused_constr; // can_fuse: box ocean only
+      const int rc = launch_tend(c, fused_constr);
+      c->bpart_out = nullptr;
       if (rc) return 1;
+      c->iq ^= 1; // as qgcm_hip_qgostep
       if (qgcm_hip_row_transform(c, 0)) return 1;
       return qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks);
     }
     case 2:
       if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
-      if (qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
       if (can_fuse_dst_unpack(c)) {
+        const bool fused_constr = !c->no_fused_constr;
+        if (!fused_constr && qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
         // the fused kernel also writes the halo messages (first / last three owned rows of po, edge row of qo)
-        if (launch_dst_unpack(c, true, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr)) return 1;
+        if (launch_dst_unpack(c, true, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr, fused_constr)) return 1;
         c->ip ^= 1;
         return 0;
       }
+      if (qgcm_hip_constr(c)) return 1;
       if (qgcm_hip_row_transform(c, 1)) return 1;
       if (qgcm_hip_unpack(c, 1)) return 1;
       if (nranks > 1) return qgcm_hip_halo_pack(c, b, cc);
