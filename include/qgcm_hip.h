@@ -184,7 +184,8 @@ int qgcm_hip_helmholtz(qgcm_hip_handle h, double *wrk, const double *boc);
  * asynchronous on the handle's stream. */
 int qgcm_hip_local_rows(qgcm_hip_handle h, int *nyl, int *joff, int *jlo, int *jhi);
 int qgcm_hip_row_transform(qgcm_hip_handle h, int inverse);
-/* number of doubles of one per-step slab summary message: 3 * nlo * ldw */
+/* number of doubles of one per-step slab summary message: 3 * nlo * ldw (+ the boundary line sums of a cyclic ocean,
+ * + 3 sums of the mixed layer once qgcm_hip_oml_init was called - query after it) */
 int qgcm_hip_thomas_msg_len(qgcm_hip_handle h);
 /* The right-hand-side independent part of the summaries (gains and unit-response sums, 4 * nlo * ldw doubles per
  * slab) is exchanged ONCE after qgcm_hip_set_grid: every rank copies its own with qgcm_hip_thomas_consts, the host
@@ -203,7 +204,7 @@ int qgcm_hip_thomas_phase(qgcm_hip_handle h, int phase, const double *gath_dev, 
 /* mass-constraint solve (src/ocisubs.F:329-370) from the area integrals thomas_phase 2 left behind */
 int qgcm_hip_constr(qgcm_hip_handle h);
 int qgcm_hip_unpack(qgcm_hip_handle h, int fuse_ocqbdy);
-/* halo messages: (3 rows of po + 1 row of qo) * nlo rows of ldx doubles each */
+/* halo messages: (3 rows of po + 1 row of qo) * nlo rows of ldx doubles each (+ 3 rows of sst with the mixed layer on) */
 int qgcm_hip_halo_msg_len(qgcm_hip_handle h);
 int qgcm_hip_halo_pack(qgcm_hip_handle h, double *to_lower_dev, double *to_upper_dev);
 int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const double *from_upper_dev);
@@ -222,7 +223,15 @@ int qgcm_hip_area_integrals(qgcm_hip_handle h, double *xin);
  *   stage 1: qgostep, row_transform(0), thomas_phase(1)                          a = summary send buffer
  *   stage 2: thomas_phase(2), constr, row_transform(1), unpack(+ocqbdy), halo_pack
  *                                                      a = summary gather buffer, b/c = halo to-lower/to-upper
- *   stage 3: halo_unpack, optional lf_average (flags & 1)                        a/b = halo from-lower/from-upper */
+ *   stage 3: halo_unpack, optional lf_average (flags & 1)                        a/b = halo from-lower/from-upper
+ * With the ocean mixed layer on the device (qgcm_hip_oml_init on every slab, before the buffers are sized) `call oml`
+ * (src/q-gcm.F:1232) runs before stage 1, in two halves around ONE more all-gather of qgcm_hip_oml_msg_len() doubles
+ * per rank (the mean entrainment is a basin-wide number, src/omlsubs.F:153):
+ *   stage 10: new sst, raw entrainment, this slab's sums                         a = send buffer (3 doubles)
+ *   stage 11: entoc from entrainment minus mean, sst buffer rotation             a = gathered sums (3 * nranks)
+ * xon(1) and the boundary line integrals of entoc then travel at the end of the stage-1 message, the edge rows of sst
+ * at the end of the halo messages. */
+int qgcm_hip_oml_msg_len(qgcm_hip_handle h);
 int qgcm_hip_slab_stage(qgcm_hip_handle h, int stage, double *a_dev, double *b_dev, double *c_dev,
                         int rank, int nranks, int flags);
 
@@ -265,7 +274,9 @@ typedef struct qgcm_hip_oml_params {
   int nb_hflux;
 } qgcm_hip_oml_params;
 /* allocates the mixed-layer state and switches it on: qgcm_hip_steps then runs oml before qgostep in
- * every step and averages sst with the other fields (src/q-gcm.F:1345-1351) */
+ * every step and averages sst with the other fields (src/q-gcm.F:1345-1351).  On a y-slab handle (arrays = local rows
+ * incl. halos, T row j between p rows j and j+1) call it before qgcm_hip_comm_init / before sizing the message buffers;
+ * qgcm_hip_slab_steps / the slab stages 10, 11 then step it. */
 int qgcm_hip_oml_init(qgcm_hip_handle h, const qgcm_hip_oml_params *p);
 /* sst, sstm (MODULE intrfac), dense (nxto,nyto) Fortran order; NULL = leave unchanged / do not fetch */
 int qgcm_hip_oml_set_state(qgcm_hip_handle h, const double *sst, const double *sstm);

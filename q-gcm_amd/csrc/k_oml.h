@@ -35,8 +35,17 @@
 #define OML_ERR 1 // tile rows per workgroup in k_oml_entoc (4: one generation of fat workgroups - 17 us instead of 9)
 
 struct QgOmlParams {
-  int nxt, nyt, nx, ny, cyc, sb, nb;
+  int nxt, nyt, nx, ny, cyc, sb, nb; // nyt, ny: rows of the LOCAL T / p arrays
   int ldt, ldx;
+  // y-slab view (whole domain: joff = 0, jX0 = jT0 = jP0 = 1, jT1 = nytg = nyt, jP1 = nyg = ny): global row = local +
+  // joff; this handle owns T rows jT0..jT1 and p rows jP0..jP1.  k_oml_step also computes T row jX0 = jT0 - 1 when a
+  // neighbour lies below: k_oml_entoc averages the entrainment of T rows j-1 and j onto p row j, and recomputing that
+  // one row (its stencil fits the three halo rows) is cheaper than another exchange; its sums count owned rows only.
+  int joff, nytg, nyg, jX0, jT0, jT1, jP0, jP1;
+  // y-slabs: the basin-wide mean entrainment needs every rank's sum: (3, nranks) from the all-gather of
+  // k_oml_ranksum's message; nullptr: the sums of this handle's own partials (whole domain)
+  const double *mean_gath;
+  int nranks;
   const double *sst, *sstm; // T grid, pitch ldt
   double *sstn;             // new sst (spare buffer)
   const double *fnet, *wekto;
@@ -54,7 +63,7 @@ struct QgOmlParams {
 // del2t(i,j) of the lagged sst, boundary variants of src/omlsubs.F:297-300 (W), 331-346 (E), 403-422 (S),
 // 437-454 (N), 466-647 (corners); the operand order of every case is the reference's.
 __device__ __forceinline__ double oml_del2t(const QgOmlParams &P, int i, int j) {
-  const int nxt = P.nxt, nyt = P.nyt;
+  const int nxt = P.nxt;
   const double *T = P.sstm;
   const long ld = P.ldt;
   const bool hasW = (i > 1) || P.cyc, hasE = (i < nxt) || P.cyc;
@@ -62,7 +71,8 @@ __device__ __forceinline__ double oml_del2t(const QgOmlParams &P, int i, int j) 
   const double w = hasW ? T[(long)(j - 1) * ld + ((i > 1 ? i - 1 : nxt) - 1)] : 0.0;
   const double e = hasE ? T[(long)(j - 1) * ld + ((i < nxt ? i + 1 : 1) - 1)] : 0.0;
   double acc, n;
-  if (j == 1) { // W, E, N, tsbdy
+  const int G = j + P.joff; // global T row: the boundary variants belong to the basin's first and last row
+  if (G == 1) { // W, E, N, tsbdy
     const double nn = T[(long)j * ld + (i - 1)];
     if (hasW) { acc = w; n = 1.0; if (hasE) { acc = acc + e; n = 2.0; } }
     else { acc = e; n = 1.0; } // a row has at least one x neighbour
@@ -71,7 +81,7 @@ __device__ __forceinline__ double oml_del2t(const QgOmlParams &P, int i, int j) 
     return acc - n * cc;
   }
   const double s = T[(long)(j - 2) * ld + (i - 1)];
-  if (j == nyt) {
+  if (G == P.nytg) {
     if (P.cyc && i == nxt && P.nb) return s + w + e - 4.0 * cc + P.tnbdy; // :630-631
     acc = s; n = 1.0; // S, W, tnbdy, E
     if (hasW) { acc = acc + w; n += 1.0; }
@@ -115,14 +125,15 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
   __shared__ double sD[DH * DW];
   __shared__ double red[12];
   const int tid = threadIdx.x;
-  const int i0 = blockIdx.x * OML_TX + 1, j0 = blockIdx.y * TH + 1;
+  const int i0 = blockIdx.x * OML_TX + 1, j0 = blockIdx.y * TH + P.jX0; // local rows jX0..jT1
   const int lx0 = tid % OML_TX, ly0 = tid / OML_TX;
   const int i = i0 + lx0;
   const int nxt = P.nxt, nyt = P.nyt;
   // del2t of the tile and its halo, each value once (dummy columns by the wall / wrap rule)
   for (int idx = tid; idx < DH * DW; idx += OML_NT) {
     const int gi = i0 - 1 + idx % DW, gj = j0 - 1 + idx / DW;
-    sD[idx] = (gj >= 1 && gj <= nyt && gi >= 0 && gi <= nxt + 1) ? oml_del2t_x(P, gi, gj) : 0.0;
+    const int gG = gj + P.joff;
+    sD[idx] = (gG >= 1 && gG <= P.nytg && gj >= 1 && gj <= nyt && gi >= 0 && gi <= nxt + 1) ? oml_del2t_x(P, gi, gj) : 0.0;
   }
   __syncthreads();
   const long ldt = P.ldt, ldx = P.ldx;
@@ -138,7 +149,8 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
   for (int r = 0; r < OML_RPT; ++r) {
     const int ly = ly0 + OML_TY * r;
     const int j = j0 + ly;
-    if (i > nxt || j > nyt) continue;
+    if (i > nxt || j > P.jT1) continue;
+    const int G = j + P.joff; // global T row
     // ---- advection, src/omlsubs.F:281-346 (rows), 370-456 (S/N rows), 458-700 (corners) ----
     double um, tm, up, tp;
     if (i == 1 && !P.cyc) { um = 0.0; tm = 0.0; }
@@ -147,16 +159,16 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
     else { up = UF(i + 1, j); tp = ST(i, j) + ST(i < nxt ? i + 1 : 1, j); }
     const double hxadv = hdxom1 * (up * tp - um * tm);
     double hyadv;
-    if (j == 1) {
-      const double vp = VF(i, 2), tp2 = ST(i, 1) + ST(i, 2);
+    if (G == 1) {
+      const double vp = VF(i, j + 1), tp2 = ST(i, j) + ST(i, j + 1);
       if (P.sb) {
-        const double vm = -rhf0hm * (TXo(i + 1, 1) + TXo(i, 1)), tm2 = ST(i, 1) + P.tsbdy;
+        const double vm = -rhf0hm * (TXo(i + 1, j) + TXo(i, j)), tm2 = ST(i, j) + P.tsbdy;
         hyadv = hdxom1 * (vp * tp2 - vm * tm2);
       } else hyadv = hdxom1 * (vp * tp2);
-    } else if (j == nyt) {
-      const double vm = VF(i, nyt), tm2 = ST(i, nyt - 1) + ST(i, nyt);
+    } else if (G == P.nytg) {
+      const double vm = VF(i, j), tm2 = ST(i, j - 1) + ST(i, j);
       if (P.nb) {
-        const double vp = -rhf0hm * (TXo(i + 1, nyt + 1) + TXo(i, nyt + 1)), tp2 = ST(i, nyt) + P.tnbdy;
+        const double vp = -rhf0hm * (TXo(i + 1, j + 1) + TXo(i, j + 1)), tp2 = ST(i, j) + P.tnbdy;
         hyadv = hdxom1 * (vp * tp2 - vm * tm2);
       } else hyadv = hdxom1 * (-vm * tm2);
     } else {
@@ -167,8 +179,8 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
     // ---- diffusion, src/omlsubs.F:733-759 ----
     const double *d = &sD[(ly + 1) * DW + (lx0 + 1)];
     const double dc = d[0], dw = d[-1], de = d[1];
-    if (j == 1) rhs = rhs + P.d2tfac * dc - P.d4tfac * (dw + de + d[DW] - 3.0 * dc);
-    else if (j == nyt) rhs = rhs + P.d2tfac * dc - P.d4tfac * (d[-DW] + dw + de - 3.0 * dc);
+    if (G == 1) rhs = rhs + P.d2tfac * dc - P.d4tfac * (dw + de + d[DW] - 3.0 * dc);
+    else if (G == P.nytg) rhs = rhs + P.d2tfac * dc - P.d4tfac * (d[-DW] + dw + de - 3.0 * dc);
     else rhs = rhs + P.d2tfac * dc - P.d4tfac * (d[-DW] + dw + de + d[DW] - 4.0 * dc);
     // ---- oml, src/omlsubs.F:101-128 ----
     const long o = (long)(j - 1) * ldt + (i - 1);
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
     const double xf = xfoent - coneno;
     sstnew = sstnew + fmax(0.0, dtonew);
     P.xfo[o] = xf;
+    if (j < P.jT0) continue; // the recomputed row below the slab: its sst and its sums belong to the neighbour
     P.sstn[o] = sstnew;
     sxfo += xf;
     scfr += (0.5 - copysign(0.5, -dtonew));
@@ -208,42 +221,48 @@ __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
   const int tid = threadIdx.x;
   // mean entrainment: the same fixed-order reduction of the partials in every workgroup
   double s[1] = {0.0};
-  for (int k = tid; k < P.nblkA; k += OML_NT) s[0] += P.partA[k];
+  if (P.mean_gath) { // y-slabs: the ranks' sums in rank order (every workgroup alike)
+    if (tid == 0)
+      for (int r = 0; r < P.nranks; ++r) s[0] += P.mean_gath[3 * r];
+  } else {
+    for (int k = tid; k < P.nblkA; k += OML_NT) s[0] += P.partA[k];
+  }
   oml_block_sums<1>(s, redm, tid);
   const double xmean = s[0] * P.ocnorm; // xfosum*ocnorm, src/omlsubs.F:153
   const int i = blockIdx.x * OML_TX + (tid % OML_TX) + 1;
-  const int nx = P.nx, ny = P.ny, nxt = P.nxt, nyt = P.nyt;
+  const int nx = P.nx, nxt = P.nxt, nyg = P.nyg;
   const long ldt = P.ldt;
   double t[3] = {0.0, 0.0, 0.0}; // xintp sum, S and N line sums
   for (int rr = 0; rr < OML_ERR; ++rr)
 #pragma unroll
   for (int r = 0; r < OML_RPT; ++r) {
-    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + 1;
-    if (i > nx || j > ny) continue;
+    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + P.jP0; // owned p rows
+    if (i > nx || j > P.jP1) continue;
+    const int G = j + P.joff; // global p row; T rows j-1 and j (local) lie below / above it
 #define XF(ii, jj) (P.xfo[(long)((jj)-1) * ldt + ((ii)-1)] - xmean)
     double en;
-    const bool xin = (i >= 2 && i <= nx - 1), yin = (j >= 2 && j <= ny - 1);
+    const bool xin = (i >= 2 && i <= nx - 1), yin = (G >= 2 && G <= nyg - 1);
     if (xin && yin) en = 0.25 * (XF(i - 1, j - 1) + XF(i, j - 1) + XF(i - 1, j) + XF(i, j)); // :162-163
     else if (xin) {
-      const int jt = (j == 1) ? 1 : nyt;
+      const int jt = (G == 1) ? j : j - 1; // the basin's first / last T row
       en = 0.5 * (XF(i - 1, jt) + XF(i, jt)); // :171-172
     } else if (P.cyc) { // :178-189: W column from the wrapped T cells, E column = W column
       if (yin) en = 0.25 * (XF(nxt, j - 1) + XF(1, j - 1) + XF(nxt, j) + XF(1, j));
       else {
-        const int jt = (j == 1) ? 1 : nyt;
+        const int jt = (G == 1) ? j : j - 1;
         en = 0.5 * (XF(nxt, jt) + XF(1, jt));
       }
     } else { // :194-202
       const int it = (i == 1) ? 1 : nxt;
       if (yin) en = 0.5 * (XF(it, j - 1) + XF(it, j));
-      else en = XF(it, (j == 1) ? 1 : nyt);
+      else en = XF(it, (G == 1) ? j : j - 1);
     }
 #undef XF
     P.entoc[(long)(j - 1) * P.ldx + (i - 1)] = en;
-    const double wx = (i == 1 || i == nx) ? 0.5 : 1.0, wy = (j == 1 || j == ny) ? 0.5 : 1.0; // xintp, src/intsubs.f:78-133
+    const double wx = (i == 1 || i == nx) ? 0.5 : 1.0, wy = (G == 1 || G == nyg) ? 0.5 : 1.0; // xintp, src/intsubs.f:78-133
     t[0] += wx * wy * en;
-    if (j == 1) t[1] += wx * en;  // src/omlsubs.F:222-231
-    if (j == ny) t[2] += wx * en;
+    if (G == 1) t[1] += wx * en;  // src/omlsubs.F:222-231
+    if (G == nyg) t[2] += wx * en;
   }
   const int b = blockIdx.y * gridDim.x + blockIdx.x;
   oml_block_sums<3>(t, red, tid);
@@ -291,6 +310,66 @@ __device__ __forceinline__ void oml_final_block(const QgOmlFinal &P, double *red
 __global__ __launch_bounds__(OML_NT) void k_oml_final(const QgOmlFinal P) {
   __shared__ double red[20];
   oml_final_block(P, red, threadIdx.x);
+}
+
+// ---- y-slabs ---------------------------------------------------------------------------------------------------------
+// The sums of a slab's per-workgroup partials (3, nblk) in the fixed order of oml_final_block: out[0..2].  One workgroup.
+// k_oml_step's go into the mixed layer's own small all-gather (the mean entrainment must be known before entoc is
+// formed), k_oml_entoc's ride at the end of the step message of the tridiagonal sweeps.
+__global__ __launch_bounds__(OML_NT) void k_oml_sum3(const double *part, int nblk, double *out) {
+  __shared__ double red[12];
+  const int tid = threadIdx.x;
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int k = tid; k < nblk; k += OML_NT) {
+    a[0] += part[k];
+    a[1] += part[nblk + k];
+    a[2] += part[2 * nblk + k];
+  }
+  oml_block_sums<3>(a, red, tid);
+  if (tid < 3) out[tid] = a[tid];
+}
+
+// xon(1), enisoc(1) / eninoc(1) and the monitors from every rank's sums, in rank order (the same on every rank):
+// gA = (3, nranks) of the mixed layer's all-gather, gB = the three numbers at gB + r*strideB of the step messages.
+__global__ void k_oml_final_slab(const double *gA, const double *gB, long strideB, int nranks, QgOmlFinal P) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double t[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int r = 0; r < nranks; ++r) {
+    t[0] += gB[r * strideB];
+    t[1] += gB[r * strideB + 1];
+    t[2] += gB[r * strideB + 2];
+    t[3] += gA[3 * r + 1];
+    t[4] += gA[3 * r + 2];
+  }
+  P.sc->xon[0] = t[0] * P.dxo * P.dyo; // src/omlsubs.F:215-216
+  if (P.cyc) {
+    P.sc->enisoc[0] = P.dxo * t[1]; // :232-233
+    P.sc->eninoc[0] = P.dxo * t[2];
+  }
+  P.diag[0] = t[3] * P.ocnorm;        // cfraoc, :207
+  P.diag[1] = t[4] * P.dxo * P.dyo;   // centoc, :208
+}
+
+// halo rows of the new sst: the first / last three owned T rows go to the lower / upper neighbour (appended to the
+// halo message of the step), three rows come back on each side.  grid: (ceil(nxt/256), 3, 2 sides)
+// (the local T array ends two rows above the slab - all the stencils need there; the third row of that message is unused)
+__global__ __launch_bounds__(256) void k_oml_halo(double *sst, int ldt, int nxt, int nyt, int jT0, int jT1, double *to_lo,
+                                                  double *to_hi, const double *from_lo, const double *from_hi, int unpack) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y, hi = blockIdx.z;
+  if (i >= nxt) return;
+  if (!unpack) {
+    double *dst = hi ? to_hi : to_lo;
+    if (!dst) return;
+    const int j = hi ? jT1 - 2 + r : jT0 + r; // local T row (1-based)
+    dst[(long)r * ldt + i] = sst[(long)(j - 1) * ldt + i];
+  } else {
+    const double *src = hi ? from_hi : from_lo;
+    if (!src) return;
+    const int j = hi ? jT1 + 1 + r : jT0 - 3 + r;
+    if (j < 1 || j > nyt) return;
+    sst[(long)(j - 1) * ldt + i] = src[(long)r * ldt + i];
+  }
 }
 
 // leapfrog averaging of the mixed-layer temperature, src/q-gcm.F:1345-1351

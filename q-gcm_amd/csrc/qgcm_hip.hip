@@ -65,6 +65,7 @@ struct qgcm_hip_ctx {
   double *ybnd = nullptr;                  // cyclic y-slabs: (2, nl) zonal-mean solution next to the zonal boundaries (k_thomas PHASE 2)
   const double *slab_gath = nullptr;       // cyclic y-slabs: the gathered step messages of the last thomas phase 2
   int slab_nranks = 1;
+  const double *oml_gath = nullptr;        // y-slabs: the gathered sums of the mixed layer's stage 10 (3, nranks)
   double *bpart_out = nullptr;             // where k_tend's extra workgroups put the boundary line sums (bpart, or the tail of the step message)
   QgThomasTab tt, tt_tmp;                  // Thomas pivot tables of the modal solves / of the last qgcm_hip_helmholtz
   double *slabDE;                          // y-slab summary constants (D, E, SP, SQ) per (mode, wavenumber)
@@ -273,7 +274,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   if (c->sc_comm) {
     QgSlabComm *m = c->sc_comm;
     if (m->comm) m->api->CommDestroy(m->comm);
-    double *cb[] = {m->th_send, m->th_gath, m->h_send, m->h_gath};
+    double *cb[] = {m->th_send, m->th_gath, m->h_send, m->h_gath, m->oml_send, m->oml_gath};
     for (double *p : cb)
       if (p) hipFree(p);
     delete m;
@@ -316,6 +317,12 @@ static int thomas_rows_per_chunk(int nrows) {
 // per-step message of one slab: the summaries of the two y sweeps; a cyclic ocean appends its boundary line sums
 static inline size_t slab_msg_len(const QgGeom &g) {
   return (size_t)TH_MSG * g.nl * g.ldw + (g.cyc ? (size_t)5 * BSUM_NB * 2 * g.nl : 0);
+}
+// ... and, with the mixed layer on the device, the three sums of its entoc pass at the very end
+static inline size_t slab_msg_len_oml(const qgcm_hip_ctx *c) { return slab_msg_len(c->g) + (c->oml.on ? 3 : 0); }
+// halo message per direction: 3 rows of po + 1 row of qo per layer, + 3 rows of the new sst with the mixed layer on
+static inline size_t halo_msg_len(const qgcm_hip_ctx *c) {
+  return (size_t)4 * c->g.nl * c->g.ldx + (c->oml.on ? (size_t)3 * c->oml.ldt : 0);
 }
 
 // Thomas pivots, exactly the recurrence of src/ocisubs.F:472-477 (box) / 577-582 (cyclic), run once on the host.
@@ -850,7 +857,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
   memset(&P, 0, sizeof(P));
   P.g = g;
   P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
-  P.gath_stride = (long)slab_msg_len(g);
+  P.gath_stride = (long)slab_msg_len_oml(c);
   if (phase == 2 && g.cyc) {
     P.ybnd = c->ybnd;
     c->slab_gath = gath;
@@ -950,7 +957,7 @@ static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q) {
     // the last rank the northern one); the solution next to the boundaries comes from k_thomas PHASE 2
     const size_t off = (size_t)TH_MSG * g.nl * g.ldw;
     Q.bpart = c->slab_gath + off;
-    Q.bpart_n = c->slab_gath + (size_t)(c->slab_nranks - 1) * slab_msg_len(g) + off;
+    Q.bpart_n = c->slab_gath + (size_t)(c->slab_nranks - 1) * slab_msg_len_oml(c) + off;
     Q.ybnd = c->ybnd;
   }
   Q.adfaco = 1.0 / (12.0 * pr2.dxo * pr2.dyo * pr2.fnot);
@@ -1273,7 +1280,7 @@ extern "C" int qgcm_hip_lf_average(qgcm_hip_handle c) {
 extern "C" int qgcm_hip_oml_init(qgcm_hip_handle c, const qgcm_hip_oml_params *p) {
   if (check_ready(c, "qgcm_hip_oml_init")) return 1;
   if (!p) QG_FAIL("qgcm_hip_oml_init: null parameters");
-  if (!c->whole) QG_FAIL("qgcm_hip_oml_init: the mixed layer is implemented for a handle that owns the whole domain");
+  if (c->sc_comm) QG_FAIL("qgcm_hip_oml_init: call before qgcm_hip_comm_init (the step and halo messages grow by the mixed layer's parts)");
   if (!(p->hmoc > 0.0) || p->toc1 == p->toc2) QG_FAIL("qgcm_hip_oml_init: need hmoc > 0 and toc(1) != toc(2)");
   const QgGeom &g = c->g;
   const int nxt = g.nxt, nyt = g.ny - 1;
@@ -1340,26 +1347,31 @@ static void fill_oml_final(qgcm_hip_ctx *c, QgOmlFinal &F, bool on) {
   memset(&F, 0, sizeof(F));
   F.partA = o.partA; F.partB = o.partB; F.nblkA = o.nblkA; F.nblkB = o.nblkB; F.cyc = c->g.cyc; F.on = on ? 1 : 0;
   F.sc = c->sc; F.diag = o.diag;
-  F.ocnorm = 1.0 / ((double)c->g.nxt * (double)(c->g.ny - 1)); // src/parameters_data.F:88
+  F.ocnorm = 1.0 / ((double)c->g.nxt * (double)(c->g.nyg - 1)); // src/parameters_data.F:88
   F.dxo = c->prm.dxo; F.dyo = c->prm.dyo;
 }
 
-// with_final = false: the final reduction rides in workgroup 0 of the tendency launch that follows (one_step)
-static int launch_oml(qgcm_hip_ctx *c, bool with_final = true) {
+static void fill_oml_params(qgcm_hip_ctx *c, QgOmlParams &P) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
   auto &o = c->oml;
   const qgcm_hip_oml_params &q = o.prm;
-  QgOmlParams P;
   memset(&P, 0, sizeof(P));
   P.nxt = g.nxt; P.nyt = g.ny - 1; P.nx = g.nx; P.ny = g.ny; P.cyc = g.cyc; P.sb = q.sb_hflux; P.nb = q.nb_hflux;
   P.ldt = o.ldt; P.ldx = g.ldx;
+  // y-slab view (k_oml.h): T row j lies between p rows j and j+1
+  P.joff = g.joff; P.nyg = g.nyg; P.nytg = g.nyg - 1;
+  P.jP0 = g.jlo; P.jP1 = g.jhi;
+  P.jT0 = g.jlo; P.jT1 = (g.jhi + g.joff == g.nyg) ? g.jhi - 1 : g.jhi;
+  P.jX0 = (g.jlo + g.joff > 1) ? P.jT0 - 1 : P.jT0;
   const int spare = 3 - o.is - o.ism;
   P.sst = o.sst[o.is]; P.sstm = o.sst[o.ism]; P.sstn = o.sst[spare];
   P.fnet = o.fnet; P.wekto = o.wekto; P.xfo = o.xfo;
   P.po1 = c->p[c->ip]; P.taux = o.taux; P.tauy = o.tauy;
   P.entoc = c->entoc;
-  P.partA = o.partA; P.partB = o.partB; P.nblkA = o.nblkA; P.nblkB = o.nblkB;
+  P.partA = o.partA; P.partB = o.partB;
+  P.nblkA = ((P.nxt + OML_TX - 1) / OML_TX) * ((P.jT1 - P.jX0 + 1 + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+  P.nblkB = ((P.nx + OML_TX - 1) / OML_TX) * ((P.jP1 - P.jP0 + 1 + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
   P.sc = c->sc; P.diag = o.diag;
   const double dxom2 = 1.0 / (pr.dxo * pr.dxo), rdxof0 = 1.0 / (pr.dxo * pr.fnot); // src/q-gcm.F:435
   P.uvgfac = q.ycexp * rdxof0;           // src/omlsubs.F:274-277
@@ -1371,27 +1383,55 @@ static int launch_oml(qgcm_hip_ctx *c, bool with_final = true) {
   P.dtoinv = 1.0 / (q.toc1 - q.toc2);
   P.entfac = q.hmoc * P.dtoinv / pr.tdto;
   P.tdto = pr.tdto; P.rrcpoc = q.rrcpoc; P.toc1 = q.toc1; P.tsbdy = q.tsbdy; P.tnbdy = q.tnbdy;
-  P.ocnorm = 1.0 / ((double)P.nxt * (double)P.nyt); // src/parameters_data.F:88
+  P.ocnorm = 1.0 / ((double)P.nxt * (double)P.nytg); // src/parameters_data.F:88
   P.dxo = pr.dxo; P.dyo = pr.dyo;
-  KTimer t(c, KN_OML);
-  dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
-  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.ny + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
+}
+
+// first half of `oml`: new sst, raw entrainment, per-workgroup partial sums.  send3 (y-slabs): this slab's three sums
+static int launch_oml_a(qgcm_hip_ctx *c, double *send3) {
+  QgOmlParams P;
+  fill_oml_params(c, P);
+  dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.jT1 - P.jX0 + 1 + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
   hipLaunchKernelGGL(k_oml_step, gA, dim3(OML_NT), 0, c->stream, P);
+  if (send3) hipLaunchKernelGGL(k_oml_sum3, dim3(1), dim3(OML_NT), 0, c->stream, (const double *)P.partA, P.nblkA, send3);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// second half: entoc from the entrainment minus its basin-wide mean (gath3 (3, nranks): every slab's sums, or nullptr
+// for a handle that owns the whole domain), then the rotation of the sst buffers
+static int launch_oml_b(qgcm_hip_ctx *c, const double *gath3, int nranks) {
+  auto &o = c->oml;
+  QgOmlParams P;
+  fill_oml_params(c, P);
+  P.mean_gath = gath3;
+  P.nranks = nranks;
+  dim3 gB((P.nx + OML_TX - 1) / OML_TX, (P.jP1 - P.jP0 + 1 + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
   hipLaunchKernelGGL(k_oml_entoc, gB, dim3(OML_NT), 0, c->stream, P);
+  HIPCHECK(hipGetLastError());
+  // rotation: sstm <- sst, sst <- new (src/omlsubs.F:125-126)
+  const int spare = 3 - o.is - o.ism;
+  o.ism = o.is;
+  o.is = spare;
+  return 0;
+}
+
+// with_final = false: the final reduction rides in workgroup 0 of the tendency launch that follows (one_step)
+static int launch_oml(qgcm_hip_ctx *c, bool with_final = true) {
+  KTimer t(c, KN_OML);
+  if (launch_oml_a(c, nullptr) || launch_oml_b(c, nullptr, 1)) return 1;
   if (with_final) {
     QgOmlFinal F;
     fill_oml_final(c, F, true);
     hipLaunchKernelGGL(k_oml_final, dim3(1), dim3(OML_NT), 0, c->stream, F);
   }
   HIPCHECK(hipGetLastError());
-  // rotation: sstm <- sst, sst <- new (src/omlsubs.F:125-126)
-  o.ism = o.is;
-  o.is = spare;
   return 0;
 }
 
 extern "C" int qgcm_hip_oml(qgcm_hip_handle c) {
   if (oml_ready(c, "qgcm_hip_oml")) return 1;
+  if (!c->whole) QG_FAIL("qgcm_hip_oml: this handle is a y-slab; the mixed layer steps with the slab stages 10 / 11");
   return launch_oml(c);
 }
 
@@ -1887,7 +1927,8 @@ extern "C" int qgcm_hip_area_integrals(qgcm_hip_handle c, double *xin) {
   return qgcm_hip_get_inv_diag(c, xin, nullptr);
 }
 
-extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? (int)slab_msg_len(c->g) : 0; }
+extern "C" int qgcm_hip_thomas_msg_len(qgcm_hip_handle c) { return c ? (int)slab_msg_len_oml(c) : 0; }
+extern "C" int qgcm_hip_oml_msg_len(qgcm_hip_handle c) { return c ? 3 : 0; }
 
 extern "C" int qgcm_hip_thomas_const_len(qgcm_hip_handle c) { return c ? TH_CST * c->g.nl * c->g.ldw : 0; }
 
@@ -1936,7 +1977,7 @@ extern "C" int qgcm_hip_unpack(qgcm_hip_handle c, int fuse_ocqbdy) {
   return 0;
 }
 
-extern "C" int qgcm_hip_halo_msg_len(qgcm_hip_handle c) { return c ? 4 * c->g.nl * c->g.ldx : 0; }
+extern "C" int qgcm_hip_halo_msg_len(qgcm_hip_handle c) { return c ? (int)halo_msg_len(c) : 0; }
 
 extern "C" int qgcm_hip_halo_pack(qgcm_hip_handle c, double *to_lower_dev, double *to_upper_dev) {
   if (check_ready(c, "qgcm_hip_halo_pack")) return 1;
@@ -1959,6 +2000,18 @@ extern "C" int qgcm_hip_halo_unpack(qgcm_hip_handle c, const double *from_lower_
   return 0;
 }
 
+// edge rows of the new sst (first / last three owned T rows) appended to the halo messages
+static int oml_halo_pack(qgcm_hip_ctx *c, double *to_lo, double *to_hi) {
+  if (!c->oml.on || (!to_lo && !to_hi)) return 0;
+  const size_t off = (size_t)4 * c->g.nl * c->g.ldx;
+  const int jT1 = (c->g.jhi + c->g.joff == c->g.nyg) ? c->g.jhi - 1 : c->g.jhi;
+  hipLaunchKernelGGL(k_oml_halo, dim3((c->g.nxt + 255) / 256, 3, 2), dim3(256), 0, c->stream, c->oml.sst[c->oml.is], c->oml.ldt, c->g.nxt,
+                     c->g.ny - 1, c->g.jlo, jT1, to_lo ? to_lo + off : nullptr, to_hi ? to_hi + off : nullptr, (const double *)nullptr,
+                     (const double *)nullptr, 0);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, double *b, double *cc, int rank, int nranks,
                                    int flags) {
   switch (stage) {
@@ -1970,34 +2023,69 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
       // box fast path: as in qgcm_hip_steps the leapfrog of dpioc is done by the tendency launch and the constraint
       // solve by the extra wave of the fused inverse-transform kernel of stage 2 (no k_constr_box launch)
       if (!c->homog_set) QG_FAIL("qgcm_hip_slab_stage: homogeneous solutions not set");
-      const bool fused_constr = can_fuse_dst_unpack(c) && !c->no_fused_constr; // can_fuse: box ocean only
+      // (with the mixed layer on, xon(1) is only complete after the all-gather: dpioc is stepped in stage 2 then)
+      const bool fused_constr = can_fuse_dst_unpack(c) && !c->no_fused_constr && !c->oml.on; // can_fuse: box ocean only
       const int rc = launch_tend(c, fused_constr);
       c->bpart_out = nullptr;
       if (rc) return 1;
       c->iq ^= 1; // as qgcm_hip_qgostep
       if (qgcm_hip_row_transform(c, 0)) return 1;
-      return qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks);
+      if (qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks)) return 1;
+      if (c->oml.on) { // the three sums of this slab's entoc pass (stage 11) ride at the end of the step message
+        QgOmlParams OP;
+        fill_oml_params(c, OP);
+        hipLaunchKernelGGL(k_oml_sum3, dim3(1), dim3(OML_NT), 0, c->stream, (const double *)OP.partB, OP.nblkB, a + slab_msg_len(c->g));
+        HIPCHECK(hipGetLastError());
+      }
+      return 0;
     }
     case 2:
       if (qgcm_hip_thomas_phase(c, 2, a, nullptr, rank, nranks)) return 1;
+      if (c->oml.on) { // xon(1), enisoc(1) / eninoc(1), monitors from every rank's sums, before the constraints use them
+        if (!c->oml_gath) QG_FAIL("qgcm_hip_slab_stage: the mixed layer's stages 10 / 11 have not run this step");
+        QgOmlFinal F;
+        fill_oml_final(c, F, true);
+        hipLaunchKernelGGL(k_oml_final_slab, dim3(1), dim3(64), 0, c->stream, c->oml_gath, (const double *)(a + slab_msg_len(c->g)),
+                           (long)slab_msg_len_oml(c), nranks, F);
+        HIPCHECK(hipGetLastError());
+      }
       if (can_fuse_dst_unpack(c)) {
-        const bool fused_constr = !c->no_fused_constr;
+        const bool fused_constr = !c->no_fused_constr && !c->oml.on;
         if (!fused_constr && qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
         // the fused kernel also writes the halo messages (first / last three owned rows of po, edge row of qo)
         if (launch_dst_unpack(c, true, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr, fused_constr)) return 1;
         c->ip ^= 1;
-        return 0;
+        return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);
       }
       if (qgcm_hip_constr(c)) return 1;
       if (qgcm_hip_row_transform(c, 1)) return 1;
       if (qgcm_hip_unpack(c, 1)) return 1;
-      if (nranks > 1) return qgcm_hip_halo_pack(c, b, cc);
-      return 0;
+      if (nranks > 1 && qgcm_hip_halo_pack(c, b, cc)) return 1;
+      return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);
     case 3:
       if (nranks > 1 && qgcm_hip_halo_unpack(c, a, b)) return 1;
+      if (nranks > 1 && c->oml.on) { // the neighbours' edge rows of the new sst sit at the end of the halo messages
+        const size_t off = (size_t)4 * c->g.nl * c->g.ldx;
+        const int jT1 = (c->g.jhi + c->g.joff == c->g.nyg) ? c->g.jhi - 1 : c->g.jhi;
+        hipLaunchKernelGGL(k_oml_halo, dim3((c->g.nxt + 255) / 256, 3, 2), dim3(256), 0, c->stream, c->oml.sst[c->oml.is], c->oml.ldt,
+                           c->g.nxt, c->g.ny - 1, c->g.jlo, jT1, (double *)nullptr, (double *)nullptr,
+                           a ? (const double *)(a + off) : nullptr, b ? (const double *)(b + off) : nullptr, 1);
+        HIPCHECK(hipGetLastError());
+      }
       if (flags & 1) return qgcm_hip_lf_average(c);
       return 0;
-    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..3");
+    // ---- ocean mixed layer on y-slabs: `call oml` (src/q-gcm.F:1232) comes before qgostep and needs the basin-wide
+    // mean entrainment half way through - one more (three numbers per rank) all-gather per step
+    case 10: // new sst, raw entrainment; a = this slab's three sums (send buffer of the mixed layer's all-gather)
+      if (oml_ready(c, "qgcm_hip_slab_stage")) return 1;
+      if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 10 needs the send buffer");
+      return launch_oml_a(c, a);
+    case 11: // a = the gathered sums (3, nranks): entoc, rotation of the sst buffers
+      if (oml_ready(c, "qgcm_hip_slab_stage")) return 1;
+      if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 11 needs the gathered sums");
+      c->oml_gath = a;
+      return launch_oml_b(c, a, nranks);
+    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..3, 10 or 11");
   }
 }
 
@@ -2038,14 +2126,15 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   m->nranks = nranks;
   const char *hp = getenv("QGCM_HIP_HALO_P2P");
   m->halo_p2p = hp && atoi(hp) != 0;
-  m->th_len = slab_msg_len(g);
-  m->halo_len = (size_t)4 * g.nl * g.ldx;
+  m->th_len = slab_msg_len_oml(c);
+  m->halo_len = halo_msg_len(c);
   c->sc_comm = m; // owned by the handle from here on (freed in qgcm_hip_destroy)
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   NCCLCHECK(api, api->CommInitRank(&m->comm, nranks, u, rank));
   struct { double **p; size_t n; } bufs[] = {{&m->th_send, m->th_len}, {&m->th_gath, m->th_len * nranks},
-                                             {&m->h_send, 2 * m->halo_len}, {&m->h_gath, 2 * m->halo_len * nranks}};
+                                             {&m->h_send, 2 * m->halo_len}, {&m->h_gath, 2 * m->halo_len * nranks},
+                                             {&m->oml_send, 4}, {&m->oml_gath, (size_t)4 * nranks}};
   for (auto &b : bufs) {
     HIPCHECK(hipMalloc((void **)b.p, b.n * sizeof(double)));
     HIPCHECK(hipMemsetAsync(*b.p, 0, b.n * sizeof(double), c->stream));
@@ -2126,6 +2215,14 @@ static int slab_step(qgcm_hip_ctx *c, int s) {
   QgSlabComm *m = c->sc_comm;
   const int r = m->rank, P = m->nranks;
   const size_t n = m->halo_len;
+  if (m->th_len != slab_msg_len_oml(c) || n != halo_msg_len(c))
+    QG_FAIL("qgcm_hip_slab_steps: the mixed layer was switched on after qgcm_hip_comm_init (message sizes differ)");
+  // 0. mixed layer (`call oml` precedes qgostep): new sst + raw entrainment, every slab's sums, entoc
+  if (c->oml.on) {
+    if (qgcm_hip_slab_stage(c, 10, m->oml_send, nullptr, nullptr, r, P, 0)) return 1;
+    NCCLCHECK(m->api, m->api->AllGather(m->oml_send, m->oml_gath, 3, ncclDouble, m->comm, c->stream));
+    if (qgcm_hip_slab_stage(c, 11, m->oml_gath, nullptr, nullptr, r, P, 0)) return 1;
+  }
   // 1. tendency, forward row transform, slab summary of the two y sweeps
   if (qgcm_hip_slab_stage(c, 1, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
   NCCLCHECK(m->api, m->api->AllGather(m->th_send, m->th_gath, m->th_len, ncclDouble, m->comm, c->stream));
@@ -2163,13 +2260,14 @@ static int slab_step(qgcm_hip_ctx *c, int s) {
 
 static int get_slab_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   const int phase = (s0 - 1) % 25;
-  const int key = (c->ip << 16) | (c->iq << 8) | phase;
+  const int omk = c->oml.on ? 1 + 3 * c->oml.is + c->oml.ism : 0; // mixed layer on/off and its buffer rotation
+  const int key = (omk << 20) | (c->ip << 16) | (c->iq << 8) | phase;
   auto it = c->slab_graphs.find(key);
   if (it != c->slab_graphs.end()) {
     *out = it->second;
     return 0;
   }
-  const int ip0 = c->ip, iq0 = c->iq;
+  const int ip0 = c->ip, iq0 = c->iq, is0 = c->oml.is, ism0 = c->oml.ism;
   hipGraph_t graph;
   HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
@@ -2177,6 +2275,8 @@ static int get_slab_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
   c->ip = ip0; // nothing ran: the rotation state is that of the block's first step
   c->iq = iq0;
+  c->oml.is = is0;
+  c->oml.ism = ism0;
   if (rc) return 1;
   HIPCHECK(e);
   hipGraphExec_t exec;
@@ -2197,6 +2297,7 @@ extern "C" int qgcm_hip_slab_steps(qgcm_hip_handle c, int s0, int n) {
     hipGraphExec_t ge;
     if (get_slab_graph(c, s, &ge)) return 1;
     HIPCHECK(hipGraphLaunch(ge, c->stream));
+    if (c->oml.on) oml_rotate(c, kGraphBlock); // the p and q rotations are back where they started, sst has moved on
     s += kGraphBlock; // 50 steps: both rotations are back where they started
     n -= kGraphBlock;
   }

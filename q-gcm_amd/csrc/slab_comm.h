@@ -62,4 +62,5 @@ struct QgSlabComm {
   size_t th_len = 0, halo_len = 0;
   double *th_send = nullptr, *th_gath = nullptr; // slab summaries of the y sweeps (k_thomas.h, TH_MSG per mode and wavenumber)
   double *h_send = nullptr, *h_gath = nullptr;   // edge rows: [to lower | to upper] per rank
+  double *oml_send = nullptr, *oml_gath = nullptr; // mixed layer: the three sums of a slab's k_oml_step (3 per rank)
 };

@@ -53,7 +53,7 @@ SYMBOLS = [
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
     "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
     "qgcm_hip_constr", "qgcm_hip_unpack",
-    "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack", "qgcm_hip_slab_stage",
+    "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack", "qgcm_hip_slab_stage", "qgcm_hip_oml_msg_len",
     "qgcm_hip_comm_unique_id", "qgcm_hip_comm_init", "qgcm_hip_slab_steps", "qgcm_hip_comm_set_halo_p2p", "qgcm_hip_comm_probe",
     "qgcm_hip_oml_init", "qgcm_hip_oml_set_state", "qgcm_hip_oml_get_state", "qgcm_hip_oml_set_forcing",
     "qgcm_hip_oml", "qgcm_hip_oml_get_diag", "qgcm_hip_set_dtopoc", "qgcm_hip_valids",
@@ -113,6 +113,7 @@ def load_library():
     L.qgcm_hip_constr.argtypes = [vp]
     L.qgcm_hip_unpack.argtypes = [vp, C.c_int]
     L.qgcm_hip_halo_msg_len.argtypes = [vp]
+    L.qgcm_hip_oml_msg_len.argtypes = [vp]
     L.qgcm_hip_halo_pack.argtypes = [vp, vp, vp]
     L.qgcm_hip_halo_unpack.argtypes = [vp, vp, vp]
     L.qgcm_hip_slab_stage.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int]

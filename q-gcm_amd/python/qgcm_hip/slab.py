@@ -249,6 +249,7 @@ class HipSlab:
         self.cst_len = self.L.qgcm_hip_thomas_const_len(self.h)
         self.halo_len = self.L.qgcm_hip_halo_msg_len(self.h)
         self.stream_ptr = self.L.qgcm_hip_stream(self.h)
+        self.oml_on = False
 
     def set_homog(self, ochom_local, cdiffo, cdhoc):
         oh, cd, ch = np.asfortranarray(ochom_local), np.asfortranarray(cdiffo), np.asfortranarray(cdhoc)
@@ -307,6 +308,42 @@ class HipSlab:
         es = np.zeros(nl - 1) if enisoc is None else np.ascontiguousarray(enisoc, dtype=np.float64)
         en = np.zeros(nl - 1) if eninoc is None else np.ascontiguousarray(eninoc, dtype=np.float64)
         check(self.L.qgcm_hip_set_cyc_forcing(self.h, float(txisoc), float(txinoc), _dp(es), _dp(en)))
+
+    # ocean mixed layer (T grid: row j between p rows j and j+1; local arrays hold rows 1..nyl-1 of the slab view) ------
+    def oml_init(self, om):
+        """Switch the mixed layer on for this slab (before SlabOcean sizes its message buffers)."""
+        from .lib import OmlParams
+        p = OmlParams()
+        p.hmoc, p.toc1, p.toc2, p.st2d, p.st4d = om.hmoc, om.toc[0], om.toc[1], om.st2d, om.st4d
+        p.ycexp, p.rrcpoc, p.tsbdy, p.tnbdy = om.ycexp, om.rrcpoc, om.tsbdy, om.tnbdy
+        p.sb_hflux, p.nb_hflux = int(om.sb_hflux), int(om.nb_hflux)
+        check(self.L.qgcm_hip_oml_init(self.h, C.byref(p)))
+        self.oml_on = True
+        self.th_len = self.L.qgcm_hip_thomas_msg_len(self.h)
+        self.halo_len = self.L.qgcm_hip_halo_msg_len(self.h)
+        self.oml_len = self.L.qgcm_hip_oml_msg_len(self.h)
+
+    def t_slice(self):
+        """Rows of a GLOBAL (nxto, nyto) T-grid array that this slab's local T array holds."""
+        return slice(self.joff, self.joff + self.nyl - 1)
+
+    def oml_set_state(self, sst, sstm):
+        """sst, sstm: GLOBAL (nxto, nyto) arrays; the local rows (incl. halo rows) are cut out here."""
+        a = [np.asfortranarray(x[:, self.t_slice()], dtype=np.float64) for x in (sst, sstm)]
+        check(self.L.qgcm_hip_oml_set_state(self.h, *[_dp(x) for x in a]))
+
+    def oml_get_state(self):
+        """Local (nxto, nyl-1) sst, sstm; owned T rows are local rows jlo..(jhi or jhi-1 on the last rank)."""
+        a = [np.zeros((self.cfg.nxto, self.nyl - 1), order="F") for _ in range(2)]
+        check(self.L.qgcm_hip_oml_get_state(self.h, *[_dp(x) for x in a]))
+        return a
+
+    def oml_set_forcing(self, fnetoc, wekto, tauxo, tauyo):
+        """GLOBAL arrays: fnetoc, wekto on the T grid (nxto, nyto); tauxo, tauyo on the p grid (nxpo, nypo)."""
+        sl = slab_slice(self.cfg.nypo, self.g0, self.g1)
+        a = [np.asfortranarray(fnetoc[:, self.t_slice()], dtype=np.float64), np.asfortranarray(wekto[:, self.t_slice()], dtype=np.float64),
+             np.asfortranarray(tauxo[:, sl], dtype=np.float64), np.asfortranarray(tauyo[:, sl], dtype=np.float64)]
+        check(self.L.qgcm_hip_oml_set_forcing(self.h, *[_dp(x) for x in a]))
 
     def set_scalars(self, s):
         s = np.ascontiguousarray(s, dtype=np.float64)
@@ -394,6 +431,11 @@ class SlabOcean:
         self.h_to_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
         self.h_from_lo = [s.new_buffer(s.halo_len) if s.rank > 0 else None for s in slabs]
         self.h_from_hi = [s.new_buffer(s.halo_len) if s.rank < self.P - 1 else None for s in slabs]
+        # mixed layer (HipSlab.oml_init on every slab BEFORE this constructor): one more small all-gather per step
+        self.oml_on = all(getattr(s, "oml_on", False) for s in slabs)
+        if self.oml_on:
+            self.om_send = [s.new_buffer(s.oml_len) for s in slabs]
+            self.om_gath = [s.new_buffer(s.oml_len * self.P) for s in slabs]
         self._settle()
         self.step_index = 1
         # the right-hand-side independent part of the slab summaries is exchanged once
@@ -430,6 +472,12 @@ class SlabOcean:
 
     def step(self, s):
         S, cm = self.slabs, self.comm
+        if self.oml_on:  # `call oml` precedes qgostep (src/q-gcm.F:1232): its mean entrainment is a basin-wide number
+            for i, x in enumerate(S):
+                x.stage(10, self.om_send[i])
+            self._comm(cm.all_gather, self.om_gath, self.om_send)
+            for i, x in enumerate(S):
+                x.stage(11, self.om_gath[i])
         for i, x in enumerate(S):  # tendency, forward row transform, slab summary of the y sweeps
             x.stage(1, self.th_send[i])
         self._comm(cm.all_gather, self.th_gath, self.th_send)

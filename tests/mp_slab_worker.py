@@ -2,7 +2,7 @@
 duplicate devices), each compared bitwise with the same decomposition run as virtual ranks inside this process.
 What this covers and the virtual-rank tests cannot: asynchronous stage calls (no synchronisation after every call),
 set-up exchanges between separate handles in separate processes, the DistComm transports.
-usage (under torch.distributed.run): mp_slab_worker.py <preset> <halo: allgather|p2p>"""
+usage (under torch.distributed.run): mp_slab_worker.py <preset> <halo: allgather|p2p> [oml]"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from qgcm_hip import hostinit, preset, synth  # noqa: E402
+from qgcm_hip import hostinit, oml_preset, preset, synth  # noqa: E402
 from qgcm_hip.slab import DistComm, HipSlab, LocalComm, SlabOcean, global_consts, partition  # noqa: E402
 
 
@@ -34,17 +34,29 @@ def main():
     parts = partition(cfg.nypo, P)
     # the reference: all P slabs as virtual ranks in this process
     vs = [HipSlab(cfg, consts, g0, g1, r, P, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+    with_oml = len(sys.argv) > 3 and sys.argv[3] == "oml"  # mixed layer on: one more small all-gather per step
+    if with_oml:
+        om = oml_preset(cfg, sb_hflux=True, nb_hflux=False)
+        sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om, seed=7)
+        wekto, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        for v in vs:
+            v.oml_init(om)
     vo = SlabOcean(cfg, vs, LocalComm(P, after=torch.cuda.synchronize))
     cyc = bool(cfg.cyclic)  # channel: the homogeneous solutions (functions of y) came with global_consts
     txis, txin = synth.tau_line_integrals(cfg, tx) if cyc else (0.0, 0.0)
     vh = None if cyc else vo.homsol()
     vo.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
-    if cyc:
-        for v in vs:
+    for v in vs:
+        if cyc:
             v.set_cyc_forcing(txis, txin)
+        if with_oml:
+            v.oml_set_state(sst, sstm)
+            v.oml_set_forcing(fnet, wekto, tx, ty)
     # this process's own slab, exchanges through torch.distributed
     g0, g1 = parts[rank]
     slab = HipSlab(cfg, consts, g0, g1, rank, P, device=0)
+    if with_oml:
+        slab.oml_init(om)
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=(sys.argv[2] != "p2p")))
     ok = True
@@ -54,11 +66,16 @@ def main():
     so.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
     if cyc:
         slab.set_cyc_forcing(txis, txin)
+    if with_oml:
+        slab.oml_set_state(sst, sstm)
+        slab.oml_set_forcing(fnet, wekto, tx, ty)
     for nst in (1, 1, 28):  # crosses the averaging after step 26
         so.steps(nst)
         vo.steps(nst)
         ok = ok and all(np.array_equal(x, y) for x, y in zip(slab.get_state(), vs[rank].get_state()))
         ok = ok and np.array_equal(slab.get_scalars(), vs[rank].get_scalars())
+        if with_oml:
+            ok = ok and all(np.array_equal(x, y) for x, y in zip(slab.oml_get_state(), vs[rank].oml_get_state()))
     fin = all(np.isfinite(x).all() for x in slab.get_state())
     t = torch.tensor([1.0 if (ok and fin) else 0.0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)

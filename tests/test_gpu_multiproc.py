@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("name,halo", [("box_small", "allgather"), ("box_small", "p2p"), ("box_med", "allgather"),
-                                       ("cyc_med", "allgather"), ("cyc_small", "p2p")])
-def test_three_processes_one_slab_each(name, halo):
-    port = 29600 + (hash((name, halo)) % 300)
+@pytest.mark.parametrize("name,halo,extra", [("box_small", "allgather", ""), ("box_small", "p2p", ""), ("box_med", "allgather", ""),
+                                             ("cyc_med", "allgather", ""), ("cyc_small", "p2p", ""),
+                                             ("box_small", "p2p", "oml"), ("cyc_small", "allgather", "oml")])
+def test_three_processes_one_slab_each(name, halo, extra):
+    port = 29600 + (hash((name, halo, extra)) % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "mp_slab_worker.py"), name, halo]
+           "--master-port", str(port), os.path.join(HERE, "mp_slab_worker.py"), name, halo] + ([extra] if extra else [])
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -133,3 +133,70 @@ def test_oml_needs_init_and_whole_domain():
             m.oml()
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("cfgname,nranks,sb,nb", [("box_small", 1, False, False), ("box_small", 2, True, True), ("box_med", 3, False, True),
+                                                  ("cyc_small", 2, True, True), ("cyc_med", 3, False, False)])
+def test_mixed_layer_on_y_slabs(cfgname, nranks, sb, nb):
+    """The mixed layer on y-slabs (virtual ranks on this one GPU): `oml` in two halves around one all-gather of three
+    numbers per rank (the mean entrainment), the T row below every slab recomputed locally (entoc averages two T rows
+    onto a p row), xon(1) and the line integrals in the step message, edge rows of sst in the halo messages.  60 steps
+    (two averagings, every sst buffer rotation) against the whole-domain handle: sst bitwise-close, fields <= 1e-10."""
+    import torch
+    from qgcm_hip import hostinit
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset(cfgname)
+    om = oml_preset(cfg, sb_hflux=sb, nb_hflux=nb)
+    m = OceanModel(cfg)
+    slabs = []
+    try:
+        consts = global_consts(cfg, None if cfg.cyclic else m.helmholtz)
+        po = synth.gaussian_eddy(cfg, noise=1e-3)
+        pom = np.asfortranarray(0.995 * po)
+        sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om, seed=7)
+        wekto, wekpo = synth.wekpo_from_tau(cfg, tx, ty)
+        nl = cfg.nlo
+        zero2, xon = np.zeros_like(wekpo), np.zeros(nl - 1)
+        m.oml_init(om)
+        m.set_p(po, pom)
+        m.set_forcing(wekpo, zero2, xon)
+        cyc = (synth.tau_line_integrals(cfg, tx) + (np.zeros(nl - 1), np.zeros(nl - 1))) if cfg.cyclic else None
+        if cyc:
+            m.set_cyc_forcing(*cyc)
+        m.oml_set_state(sst, sstm)
+        m.oml_set_forcing(fnet, wekto, tx, ty)
+        st = m.get_state()
+        scal = m.get_scalars()
+        parts = partition(cfg.nypo, nranks)
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+        for sl in slabs:
+            sl.oml_init(om)
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.scatter_state(st[0], st[1], st[2], st[3], wekpo, zero2, xon, scal)
+        for sl in slabs:
+            if cyc:
+                sl.set_cyc_forcing(*cyc)
+            sl.oml_set_state(sst, sstm)
+            sl.oml_set_forcing(fnet, wekto, tx, ty)
+        for nst in (1, 59):
+            so.steps(nst)
+            m.steps(nst)
+            got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+            for g0, g1, fields in so.gather_local():
+                for dst, src in zip(got, fields):
+                    dst[:, g0 - 1:g1, :] = src
+            for f, x, y in zip(FIELDS, got, m.get_state()):
+                assert relerr(x, y) < 1e-10, (f, nst)
+            ga, gb = m.oml_get_state()
+            for sl in slabs:
+                la, lb = sl.oml_get_state()
+                t1 = min(sl.g1, cfg.nypo - 1)  # owned T rows g0..t1 (global, 1-based)
+                loc = slice(sl.g0 - 1 - sl.joff, t1 - sl.joff)
+                assert relerr(la[:, loc], ga[:, sl.g0 - 1:t1]) < 1e-12, (sl.rank, nst)
+                assert relerr(lb[:, loc], gb[:, sl.g0 - 1:t1]) < 1e-12, (sl.rank, nst)
+        for sl in slabs:
+            assert np.array_equal(sl.get_scalars(), slabs[0].get_scalars())
+    finally:
+        for sl in slabs:
+            sl.close()
+        m.close()

@@ -570,14 +570,16 @@ def test_full_size_socn5_cyclic_vs_oracle():
         o.close()
 
 
-@pytest.mark.parametrize("name,graph", [("box_small", False), ("box_small", True), ("cyc_small", False), ("cyc_small", True)])
-def test_library_issued_exchanges_one_rank(name, graph, monkeypatch):
+@pytest.mark.parametrize("name,graph,with_oml", [("box_small", False, False), ("box_small", True, False), ("cyc_small", False, False),
+                                                 ("cyc_small", True, False), ("box_small", False, True), ("box_small", True, True)])
+def test_library_issued_exchanges_one_rank(name, graph, with_oml, monkeypatch):
     """qgcm_hip_slab_steps: the distributed step with the RCCL exchanges issued by the library
     itself, on a real (one-rank) RCCL communicator -- all a one-GPU box can hold; eager and as
     50-step HIP graphs that contain the collectives.  Bitwise equal to the same slab kernels
-    driven stage by stage from Python (the path the virtual-rank tests pin to the oracle).  Box and cyclic ocean."""
+    driven stage by stage from Python (the path the virtual-rank tests pin to the oracle).  Box and cyclic ocean,
+    and with the ocean mixed layer on (its own small all-gather inside the step, three graphs for the sst rotation)."""
     import torch
-    from qgcm_hip import hostinit, synth
+    from qgcm_hip import hostinit, oml_preset, synth
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, rccl_unique_id
     monkeypatch.setenv("QGCM_HIP_SLAB_GRAPH", "1" if graph else "0")
     cfg = preset(name)
@@ -594,18 +596,27 @@ def test_library_issued_exchanges_one_rank(name, graph, monkeypatch):
         qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
         scal = hostinit.constr(cfg, consts["amatoc"], po, po)
         out = []
+        if with_oml:
+            om = oml_preset(cfg, sb_hflux=True, nb_hflux=True)
+            sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om, seed=3)
+            wekto, wek = synth.wekpo_from_tau(cfg, tx, ty)
         for native in (False, True):
             sl = HipSlab(cfg, consts, 1, cfg.nypo, 0, 1, sync_each_call=not native)
             slabs.append(sl)
+            if with_oml:
+                sl.oml_init(om)
             so = SlabOcean(cfg, [sl], LocalComm(1, after=torch.cuda.synchronize))
             so.scatter_state(po, po, qo, qo, wek, zero2, xon, scal)
             if cfg.cyclic:
                 sl.set_cyc_forcing(txis, txin)
+            if with_oml:
+                sl.oml_set_state(sst, sstm)
+                sl.oml_set_forcing(fnet, wekto, tx, ty)
             if native:
                 so.use_library_exchanges(rccl_unique_id())
-            so.steps(57, s0=1)   # graph mode: one 50-step block + 7 eager steps
+            so.steps(107 if with_oml else 57, s0=1)   # graph mode: 50-step block(s) + 7 eager steps
             sl.sync()
-            out.append((sl.get_state(), sl.get_scalars()))
+            out.append((sl.get_state() + (sl.oml_get_state() if with_oml else []), sl.get_scalars()))
         for x, y in zip(out[0][0], out[1][0]):
             assert np.array_equal(x, y)
         assert np.array_equal(out[0][1], out[1][1])
