@@ -193,7 +193,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p, nsteps, nwarm, bid):
+def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p, nsteps, nwarm, bid, with_oml=False):
     """A secondary multi-GPU figure: the basin `cfg` cut into `world` y-slabs, one per rank, stepped by the driver
     the headline measurement settled on (library-issued RCCL exchanges if they were verified there, else
     torch.distributed).  Returns basin steps/s etc. (max over ranks); every rank must call it (collective)."""
@@ -210,6 +210,12 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
     scal = hostinit.constr(cfg, consts["amatoc"], po, po)
     g0, g1 = partition(cfg.nypo, world)[rank]
     slab = HipSlab(cfg, consts, g0, g1, rank, world, device=local_rank)
+    if with_oml:  # ocean mixed layer on the slabs: one more (three numbers per rank) all-gather per step
+        from qgcm_hip import oml_preset
+        om = oml_preset(cfg)
+        sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om)
+        wekto, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        slab.oml_init(om)
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=not halo_p2p))
     if not cfg.cyclic:
@@ -224,6 +230,9 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
     so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
     if cfg.cyclic:
         slab.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
+    if with_oml:
+        slab.oml_set_state(sst, sstm)
+        slab.oml_set_forcing(fnet, wekto, tx, ty)
     del po, qo, wek, consts
     t_setup = time.perf_counter() - t_setup
     so.steps(nwarm, s0=1)
@@ -440,6 +449,12 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                                                   "NAtl 1km ocean-only, 3 layers, y-slabs over %d GPUs" % world)
             except Exception as e:  # noqa: BLE001
                 extra["natl1km"] = {"error": repr(e)}
+        # (2b) the fixed NAtl 5 km basin with the ocean mixed layer on the slabs (three exchanges per step)
+        try:
+            extra["strong_scaling_natl5_mixed_layer"] = slab_secondary(cfg5, world, rank, local_rank, barrier, lib_ok, p2p, 200, 60,
+                                                                       "NAtl 5km + ocean mixed layer, fixed basin over %d GPUs" % world, with_oml=True)
+        except Exception as e:  # noqa: BLE001
+            extra["strong_scaling_natl5_mixed_layer"] = {"error": repr(e)}
         # (3) BASELINE configs[2]: Southern Ocean 5 km periodic channel (4609 x 577 x 3) cut into `world` slabs
         try:
             extra["socn5_cyclic_slabs"] = slab_secondary(preset("socn5"), world, rank, local_rank, barrier, lib_ok, p2p, 200, 40,
