@@ -56,6 +56,21 @@ def test_homsol_with_oracle_solver(case):
         o.close()
 
 
+def test_channel_homsol_from_the_column_solver(case):
+    """The homogeneous solutions of a channel depend on y only, so y-slab set-up solves ONE tridiagonal system per mode
+    on the host (hostinit.helmholtz_cyc_column) instead of calling a whole-domain Helmholtz solver: against the golden
+    vectors of the reference's homsol (conhoms.F:376-543)."""
+    cfg, g = case
+    if not cfg.cyclic:
+        pytest.skip("box ocean: homsol runs on the slabs themselves (SlabOcean.homsol)")
+    h = hostinit.homsol_cyc(cfg, g["c_rdm2oc"], g["c_bd2oc"], g["c_yporel"], lambda rhs, boc: hostinit.helmholtz_cyc_column(cfg, rhs, boc))
+    big = max(np.abs(g["h_hc1soc"]).max(), np.abs(g["h_hc2noc"]).max())
+    for k in ("pch1oc", "pch2oc", "pbhoc", "aipcho", "hbsioc", "aipbho"):
+        assert relerr(h[k], g["h_" + k]) < 1e-12, k
+    for k in ("hc1soc", "hc2soc", "hc1noc", "hc2noc"):
+        assert np.abs(h[k] - g["h_" + k]).max() / big < 1e-12, k
+
+
 def test_wekpo_matches_oracle_restatement(case):
     cfg, g = case
     tx, ty = synth.wind_stress(cfg)
