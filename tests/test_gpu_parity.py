@@ -156,6 +156,64 @@ def test_random_state_vs_oracle(case):
         o.close()
 
 
+@pytest.mark.parametrize("nlo,cyclic", [(2, False), (4, False), (2, True), (4, True)])
+def test_fast_kernels_with_two_and_four_layers(nlo, cyclic):
+    """The wave-per-row-pair kernels (nxto = 192 = 64*3) and their fused inverse-transform / unpack / constraint-wave
+    forms are templates on the number of layers; the presets only carry nlo = 3.  Two and four layers (the maximum of
+    the ABI), box and cyclic, 30 steps incl. an averaging from a noisy state, whole path and graph replay vs the oracle;
+    the box cases also as two y-slabs."""
+    import torch
+    from qgcm_hip import OceanModel, hostinit, synth
+    from qgcm_hip.config import OceanConfig
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    lay = {2: dict(hoc=(500.0, 3500.0), gpoc=(0.02,), ah2oc=(0.0, 0.0), ah4oc=(1.2e10,) * 2),
+           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4)}[nlo]
+    base = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True) if cyclic else dict(fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
+    cfg = OceanConfig("nl%d_%s" % (nlo, "cyc" if cyclic else "box"), 12 if cyclic else 16, 10, 12, 4 if cyclic else 6, 16, nlo,
+                      dxo=2.5e4, dta=240.0, **lay, **base)
+    assert cfg.nxto == 192
+    o = make_oracle(cfg)
+    m = OceanModel(cfg)
+    slabs = []
+    try:
+        po = synth.gaussian_eddy(cfg, noise=2e-2, seed=11)
+        pom = np.asfortranarray(0.99 * po)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        ent = np.asfortranarray(1e-7 * np.cos(np.arange(cfg.nxto) * 2 * np.pi / cfg.nxto)[:, None] * np.ones(cfg.nypo)[None, :])
+        ent = np.asfortranarray(np.vstack([ent, ent[:1]]))
+        xon = np.zeros(nlo - 1)
+        xon[0] = 3e2
+        for mod in (m, o):
+            mod.set_p(po, pom)
+            mod.set_forcing(wek, ent, xon)
+            if cyclic:
+                mod.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx), np.full(nlo - 1, 2e-4), np.full(nlo - 1, -1e-4))
+        st0, scal0 = m.get_state(), m.get_scalars()
+        m.steps(30, s0=1)
+        o.steps(1, 30)
+        for f, x, y in zip(FIELDS, m.get_state(), o.get_state()):
+            assert relerr(x, y) < 1e-10, (f, nlo, cyclic)
+        if not cyclic:
+            consts = global_consts(cfg, o.helmholtz)
+            parts = partition(cfg.nypo, 2)
+            slabs = [HipSlab(cfg, consts, g0, g1, r, 2, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+            so = SlabOcean(cfg, slabs, LocalComm(2, after=torch.cuda.synchronize))
+            so.scatter_state(st0[0], st0[1], st0[2], st0[3], wek, ent, xon, scal0)
+            so.steps(30, s0=1)
+            got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+            for g0, g1, fields in so.gather_local():
+                for dst, src in zip(got, fields):
+                    dst[:, g0 - 1:g1, :] = src
+            for f, x, y in zip(FIELDS, got, o.get_state()):
+                assert relerr(x, y) < 1e-10, (f, nlo, "slabs")
+    finally:
+        for sl in slabs:
+            sl.close()
+        m.close()
+        o.close()
+
+
 def test_fast_dst_grid_vs_oracle():
     """box_med has nxto = 192 = 64*3 and therefore runs the wave-per-row-pair DST
     kernel (k_dst64); check the solver and whole steps against the CPU oracle, and
