@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
 DROP = os.path.join(ROOT, "q-gcm_amd", "fortran", "dropin")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from dropin_cases import CASES, RUNS, golden_name, prepare_case  # noqa: E402
+from dropin_cases import CASES, RUNS, THREADS, golden_name, prepare_case  # noqa: E402
 
 for cfg, (dims, mode) in CASES.items():
     subprocess.check_call([os.path.join(DROP, "build_dropin.sh"), cfg] + [str(x) for x in dims] + [mode],
@@ -25,7 +25,7 @@ for cfg, (dims, mode) in CASES.items():
       with tempfile.TemporaryDirectory() as d:
         prepare_case(cfg, d, nsteps)
         exe = os.path.join(ROOT, "q-gcm_amd", "fortran", "_dropin", cfg, "q-gcm_ref")
-        env = dict(os.environ, OMP_NUM_THREADS="2", OMP_STACKSIZE="512M")
+        env = dict(os.environ, OMP_NUM_THREADS=str(THREADS[cfg]), OMP_STACKSIZE="512M")
         log = subprocess.run("ulimit -s unlimited; exec %s" % exe, shell=True, cwd=d, env=env, stdout=subprocess.PIPE,
                              stderr=subprocess.STDOUT, text=True)
         assert log.returncode == 0 and "End of run" in log.stdout, log.stdout[-2000:]

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from common import GOLDEN, relerr
-from dropin_cases import CASES, DROP, RUNS, exe_path, golden_name, prepare_case
+from dropin_cases import CASES, DROP, RUNS, THREADS, exe_path, golden_name, prepare_case
 from qgcm_hip import config, restart
 
 HAVE_REF = os.path.isdir("/root/reference/src")
@@ -67,7 +67,7 @@ def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_p
     mode = CASES[cfg][1]
     d = str(tmp_path)
     prepare_case(cfg, d, nsteps)
-    env = dict(os.environ, OMP_NUM_THREADS="2", OMP_STACKSIZE="512M")
+    env = dict(os.environ, OMP_NUM_THREADS=str(THREADS[cfg]), OMP_STACKSIZE="512M")
     r = subprocess.run("ulimit -s unlimited 2>/dev/null; exec %s" % exe, shell=True, cwd=d, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "End of run" in r.stdout, r.stdout[-3000:]
