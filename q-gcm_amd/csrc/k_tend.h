@@ -24,8 +24,7 @@
 // with -ffp-contract=off, so qgostep reproduces the CPU reference bit for bit.
 //
 // Algorithmic HBM traffic: read pom,po,qo,qom (4 nl) + wekpo,entoc,ddynoc (3),
-// write qo (nl) + wrk (nl)  ->  (6 nl + 3) N doubles = 21 N for nl = 3; entoc / ddynoc are skipped when the host
-// knows them to be identically zero (flat bottom; no entrainment forcing): 19 N for the ocean-only double gyre
+// write qo (nl) + wrk (nl)  ->  (6 nl + 3) N doubles = 21 N for nl = 3
 // (SURVEY 8d counts 24 N because the reference also rewrites qom; here the
 // q buffers rotate instead).
 #pragma once
@@ -156,8 +155,8 @@ __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTilin
     const double *pb = P.pom + fs * (NL - 1) + o;
     d2bot = P.bcfaco * (pb[-1] - pb[0]);
     wek = P.wekpo[o];
-    ent = P.has_ent ? P.entoc[o] : 0.0;
-    ddy = P.has_topo ? P.ddynoc[o] : 0.0;
+    ent = P.entoc[o];
+    ddy = P.ddynoc[o];
   }
   tend_point<NL, false>(P, gi, gj, dq, d2bot, qm, qo, wek, ent, ddy);
 }
@@ -326,8 +325,8 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
         bool in = gi <= T.imax && gj <= T.jmax;
         const int o = in ? (gj - 1) * ldx + (gi - 1) : 0; // clamped: unconditional loads, values unused when !in
         e_wek[r] = P.wekpo[o];
-        e_ent[r] = P.has_ent ? P.entoc[o] : 0.0;   // identically zero fields are not read (QgTendParams)
-        e_ddy[r] = P.has_topo ? P.ddynoc[o] : 0.0;
+        e_ent[r] = P.entoc[o];
+        e_ddy[r] = P.ddynoc[o];
 #pragma unroll
         for (int kk = 0; kk < NL; ++kk) e_qm[kk][r] = P.qnew[fs * kk + o];
       }

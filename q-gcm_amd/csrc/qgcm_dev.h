@@ -69,9 +69,6 @@ struct QgTendParams {
   // workgroup of the fused inverse-transform kernel (k_dst64_unpack<.., CONSTR>) without a launch of its own
   int upd_dpi;
   double gpoc[QG_MAXL];
-  // 0: the field is identically zero (flat bottom / no entrainment forcing and no device mixed layer): k_tend then
-  // does not read it - same arithmetic with the constant 0.0, so bitwise the result of reading the zeros
-  int has_topo, has_ent;
 };
 
 struct QgDstParams {

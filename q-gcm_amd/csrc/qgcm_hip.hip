@@ -83,7 +83,6 @@ struct qgcm_hip_ctx {
   QgConstr cs;
   bool grid_set, homog_set;
   bool geom_set = false; // yporel / ddynoc are on the device (qgcm_hip_set_geometry or set_grid)
-  bool has_topo = false, has_ent = false; // ddynoc / entoc hold something other than zeros (k_tend skips all-zero fields)
   bool whole; // the handle owns the whole domain (no y-slab neighbours)
   bool dst_single = false; // generic row kernels run single-buffer (in-place) stages
   int fft3 = 0;            // long rows: three-stage register-radix plan of k_fft3.h (0 = none; index into QG_FFT3_PLANS)
@@ -402,8 +401,6 @@ extern "C" int qgcm_hip_set_geometry(qgcm_hip_handle c, const double *yporel, co
   drop_graphs(c);
   HIPCHECK(hipMemcpy(c->yporel, yporel, sizeof(double) * g.ny, hipMemcpyHostToDevice));
   if (ddynoc) {
-    c->has_topo = false;
-    for (size_t i = 0; i < (size_t)g.nx * g.ny && !c->has_topo; ++i) c->has_topo = (ddynoc[i] != 0.0);
     if (upload2d(c, c->ddynoc, g.ldx, ddynoc, g.nx, g.ny)) return 1;
   }
   c->geom_set = true;
@@ -595,13 +592,7 @@ extern "C" int qgcm_hip_set_forcing(qgcm_hip_handle c, const double *wekpo, cons
   if (!c) QG_FAIL("qgcm_hip_set_forcing: null handle");
   const QgGeom &g = c->g;
   if (wekpo && upload2d(c, c->wekpo, g.ldx, wekpo, g.nx, g.ny)) return 1;
-  if (entoc) {
-    bool any = false;
-    for (size_t i = 0; i < (size_t)g.nx * g.ny && !any; ++i) any = (entoc[i] != 0.0);
-    if (any != c->has_ent) drop_graphs(c); // captured tendency launches carry the flag
-    c->has_ent = any;
-    if (upload2d(c, c->entoc, g.ldx, entoc, g.nx, g.ny)) return 1;
-  }
+  if (entoc && upload2d(c, c->entoc, g.ldx, entoc, g.nx, g.ny)) return 1;
   if (xon) {
     HIPCHECK(hipMemcpyAsync((char *)c->sc + offsetof(QgScalars, xon), xon, sizeof(double) * (g.nl - 1), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -749,8 +740,6 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   P.qo = c->q[c->iq];
   P.qnew = c->q[c->iq ^ 1];
   P.wekpo = c->wekpo; P.entoc = c->entoc; P.ddynoc = c->ddynoc; P.yporel = c->yporel;
-  P.has_topo = c->has_topo ? 1 : 0;
-  P.has_ent = (c->has_ent || c->oml.on) ? 1 : 0; // the device mixed layer writes entoc every step
   P.wrk = c->wrk; P.sc = c->sc; P.bsum = nullptr;
   // scalar prologue of qgostep, src/qgosubs.F:76-82, and ocadif, :276-277
   P.adfaco = 1.0 / (12.0 * pr.dxo * pr.dyo * pr.fnot);
