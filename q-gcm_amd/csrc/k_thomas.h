@@ -225,9 +225,8 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     b[t] = a * b[t]; // the backward sweep only needs a*bet
   }
   // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
-  // (the chunk gain is formed again in descending order rather than reused from the forward sweep: the zonal-mean
-  // barotropic column of a channel is nearly singular, and with the reused product the coupled drop-in moved from
-  // 4e-15 to 3e-12 of the reference after one step)
+  // (the chunk gain is formed again, in descending order; reusing the forward product would save R multiplies and
+  // change the rounding of the composed inflows)
   C = 0.0;
   D = 1.0;
 #pragma unroll
