@@ -101,3 +101,34 @@ def test_slab_handles_refuse_whole_domain_entry_points():
             sl.stage(4)
     finally:
         sl.close()
+
+
+def test_mixed_layer_on_slabs_misuse():
+    """y-slab handles: the one-call `oml` is for whole-domain handles, the slab stages 10 / 11 need qgcm_hip_oml_init,
+    and the mixed layer must be switched on before the communicator sizes the messages."""
+    import torch
+    from qgcm_hip import oml_preset
+    from qgcm_hip.slab import HipSlab, global_consts, partition, rccl_unique_id
+    cfg = preset("box_small")
+    consts = global_consts(cfg, lambda rhs, boc: np.zeros_like(rhs))  # any homogeneous solutions will do here
+    (g0, g1), _ = partition(cfg.nypo, 2)
+    sl = HipSlab(cfg, consts, g0, g1, 0, 2)
+    try:
+        buf = sl.new_buffer(64)
+        torch.cuda.synchronize()
+        with pytest.raises(QgcmHipError, match="qgcm_hip_oml_init has not been called"):
+            sl.stage(10, buf)
+        n0, h0 = sl.th_len, sl.halo_len
+        sl.oml_init(oml_preset(cfg))
+        assert sl.th_len == n0 + 3 and sl.halo_len == h0 + 3 * ((cfg.nxto + 15) // 16 * 16)
+        with pytest.raises(QgcmHipError, match="y-slab"):
+            check(sl.L.qgcm_hip_oml(sl.h))
+    finally:
+        sl.close()
+    whole = HipSlab(cfg, consts, 1, cfg.nypo, 0, 1)
+    try:
+        whole.comm_init(rccl_unique_id())
+        with pytest.raises(QgcmHipError, match="before qgcm_hip_comm_init"):
+            whole.oml_init(oml_preset(cfg))
+    finally:
+        whole.close()
