@@ -39,15 +39,32 @@ static_assert(TH_NC == 64 && TH_KW == 16, "the chunk scan maps 64 chunks to the 
 
 // Inclusive scan of affine maps over the 64 lanes of a wave (lane = position in
 // sweep order).  On return (Cs, Ds) is the composition of positions 0..lane.
-__device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    double Cp = __shfl_up(Cs, off), Dp = __shfl_up(Ds, off);
-    if (lane >= off) {
-      Cs = Cs + Ds * Cp;
-      Ds = Ds * Dp;
-    }
+// DPP moves instead of ds_bpermute shuffles (VALU only, a few cycles instead of an LDS-pipe round trip per step):
+// shifts by 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows
+// 2 and 3.  The composition is not commutative: the map taken from the lower lanes is always applied first.
+template <int CTRL>
+__device__ __forceinline__ double th_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ void th_scan_step(double &Cs, double &Ds, bool take) {
+  const double Cp = th_dpp<CTRL>(Cs), Dp = th_dpp<CTRL>(Ds);
+  if (take) {
+    Cs = Cs + Ds * Cp;
+    Ds = Ds * Dp;
   }
+}
+__device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
+  const int rl = lane & 15;
+  th_scan_step<0x111>(Cs, Ds, rl >= 1);        // row_shr:1
+  th_scan_step<0x112>(Cs, Ds, rl >= 2);        // row_shr:2
+  th_scan_step<0x114>(Cs, Ds, rl >= 4);        // row_shr:4
+  th_scan_step<0x118>(Cs, Ds, rl >= 8);        // row_shr:8
+  th_scan_step<0x142>(Cs, Ds, (lane & 16) != 0); // row_bcast:15 -> rows 1 and 3
+  th_scan_step<0x143>(Cs, Ds, lane >= 32);     // row_bcast:31 -> rows 2 and 3
 }
 
 // PHASE 0  whole column in this handle: zero inflow at both ends, 1 read + 1 write.
