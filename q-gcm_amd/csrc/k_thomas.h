@@ -228,7 +228,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const double Cf_tot = __shfl(Cs, 63), D_tot = __shfl(Ds, 63);
   {
     // value entering chunk `lane` = scanned map of chunk lane-1 applied to uin
-    double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
+    double Cprev = th_dpp<0x138>(Cs), Dprev = th_dpp<0x138>(Ds); // wave_shr:1 (lane 0 is not used)
     sIn[lane][wv] = (lane == 0) ? uin : Cprev + Dprev * uin;
   }
   __syncthreads();
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   affine_scan(Cs, Ds, lane);
   const double Cb_tot = __shfl(Cs, 63); // first value of the zero-inflow backward sweep
   {
-    double Cprev = __shfl_up(Cs, 1), Dprev = __shfl_up(Ds, 1);
+    double Cprev = th_dpp<0x138>(Cs), Dprev = th_dpp<0x138>(Ds); // wave_shr:1 (lane 0 is not used)
     sIn[cr][wv] = (lane == 0) ? vin : Cprev + Dprev * vin;
   }
   __syncthreads();
