@@ -285,6 +285,20 @@ __device__ __forceinline__ void constr_cyc_partB(const QgCycConstrParams &P, int
   }
 }
 
+// part B alone, reading the new constraint vectors part A left in the scalars (k_rfft_cyc's extra workgroup)
+__device__ void rfft_cyc_constr_partB(const QgCycConstrParams *Q, int lane) {
+  double c1[QG_MAXL], c2[QG_MAXL], c3, ocs[QG_MAXL], ocn[QG_MAXL];
+  for (int k = 0; k < Q->g.nl; ++k) {
+    ocs[k] = Q->sc->ocncs[k];
+    ocn[k] = Q->sc->ocncn[k];
+  }
+  switch (Q->g.nl) {
+    case 2: constr_cyc_partB<2>(*Q, lane, true, ocs, ocn, c1, c2, c3); break;
+    case 3: constr_cyc_partB<3>(*Q, lane, true, ocs, ocn, c1, c2, c3); break;
+    default: constr_cyc_partB<4>(*Q, lane, true, ocs, ocn, c1, c2, c3); break;
+  }
+}
+
 // both parts in one launch (stand-alone atinvq / ocinvq, generic row sizes)
 template <int NL>
 __global__ __launch_bounds__(64) void k_constr_cyc(const QgCycConstrParams P) {

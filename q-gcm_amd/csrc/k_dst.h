@@ -398,9 +398,18 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
 // grid: (ceil(nrows/2), nlayers); dynamic LDS: 2*N cplx + 2*DST_NT doubles
 // ---------------------------------------------------------------------------
 #define RFFT_NT 512
+// defined in k_cyclic.h (included after this file): part B of the cyclic constraint algebra by one wave, all layer counts
+__device__ void rfft_cyc_constr_partB(const struct QgCycConstrParams *Q, int lane);
+
 template <bool INV, class PLAN = FftPlanNatural, int NT = RFFT_NT>
 __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  if (INV && P.cycq && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup of the inverse launch inside qgcm_hip_steps: c1, c2, c3 and the dpioc step from the
+    // zonal-mean column (ksum, ybnd - nothing of wrk), while the other workgroups transform the rows
+    if (blockIdx.y == 0 && threadIdx.x < 64) rfft_cyc_constr_partB(P.cycq, threadIdx.x);
+    return;
+  }
   const int N = P.N, H = N / 2;
   const bool single = PLAN::three_stage || P.single != 0;
   cplx *A = reinterpret_cast<cplx *>(smem_raw);

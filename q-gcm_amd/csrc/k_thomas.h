@@ -284,6 +284,16 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
       if (kok && r < nr) wbase[off0 + (unsigned)(t * ldw)] = ft * w[t];
     }
   }
+  if (PHASE == 0 && P.ybnd && k == 0) {
+    // cyclic constraints: the zonal-mean solution next to the two zonal boundaries (rows 2 and nypo-1) goes to a side
+    // buffer, so that part B of the constraint algebra does not have to read wrk - which the in-place inverse rows of
+    // the generic sizes overwrite - and can ride in that launch
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      if (r0 + t == 0) P.ybnd[2 * m] = ft * w[t];
+      if (r0 + t == nr - 1) P.ybnd[2 * m + 1] = ft * w[t];
+    }
+  }
   if (PHASE == 2) return; // the basin-wide column sums came from the summaries
   // column sum of this slab: chunks in a fixed order (lanes of wave wv = chunks of wavenumber kq)
   sC[c][kk] = colsum;

@@ -83,6 +83,9 @@ struct QgDstParams {
   int nlayers;            // layers to process (nl, or 1 for helmholtz())
   int layer0;             // first layer (mode) of this launch
   int single;             // generic kernels: one LDS buffer, in-place stages (long rows: two workgroups per CU)
+  // generic cyclic inverse rows inside qgcm_hip_steps: one extra workgroup (blockIdx.x == gridDim.x - 1) runs part B of
+  // the constraint algebra (k_cyclic.h) instead of a launch of its own; nullptr otherwise
+  const struct QgCycConstrParams *cycq;
 };
 
 struct QgThomasParams {

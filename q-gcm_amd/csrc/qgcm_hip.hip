@@ -787,7 +787,8 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   return 0;
 }
 
-static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, int layer0 = 0, hipStream_t st = nullptr) {
+static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, int layer0 = 0, hipStream_t st = nullptr,
+                      bool cyc_part_b = false) {
   if (!st) st = c->stream;
   const QgGeom &g = c->g;
   QgDstParams P;
@@ -807,6 +808,11 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   const int npairs = (nrows + 1) / 2;
   dim3 grid(npairs, nlayers);
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
+  if (cyc_part_b) { // generic cyclic inverse rows: one extra workgroup runs part B of the constraint algebra
+    if (!inverse || !g.cyc || !c->d_cycq) QG_FAIL("launch_dst: part B rides in the inverse rows of a cyclic ocean with homogeneous solutions");
+    P.cycq = c->d_cycq;
+    grid.x += 1;
+  }
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
   if (c->fft3 && !c->force_generic_dst) {
     // long rows: three in-place register-radix stages (k_fft3.h)
@@ -863,7 +869,8 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
     c->slab_gath = gath;
     c->slab_nranks = nranks;
   } else if (phase == 0) {
-    c->slab_gath = nullptr; // whole-column solve: the constraint algebra reads bpart and wrk
+    c->slab_gath = nullptr; // whole-column solve: the constraint algebra reads bpart
+    if (g.cyc && nlayers == g.nl) P.ybnd = c->ybnd; // ... and the zonal-mean rows next to the boundaries from here
   }
   P.slabDE = c->slabDE;
   P.cgath = (nranks == 1) ? c->slabDE : c->th_cgath; // a lone slab is its own rank 0
@@ -952,6 +959,7 @@ static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q) {
   memset(&Q, 0, sizeof(Q));
   Q.g = g; Q.ksum = c->ksum; Q.wrk = c->wrk; Q.sc = c->sc; Q.cs = c->cs;
   Q.bpart = Q.bpart_n = c->bpart;
+  Q.ybnd = c->ybnd; // k_thomas (PHASE 0 and PHASE 2 alike) leaves the zonal-mean rows next to the boundaries there
   if (c->slab_gath) {
     // y-slab stages: the boundary line sums travel at the end of the step messages (rank 0 owns the southern boundary,
     // the last rank the northern one); the solution next to the boundaries comes from k_thomas PHASE 2
@@ -1210,6 +1218,18 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
     if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, fc)) return 1;
     if (!fc && launch_constr(c)) return 1;
     if (launch_rfft_unpack(c, fuse_bdy, fc)) return 1;
+    c->ip ^= 1;
+    return 0;
+  }
+  // (the wave-per-row-pair kernels of k_rfft64.h have no such extra workgroup: they are fused with the unpack step
+  //  above unless that is switched off, and then keep the stand-alone constraint launch)
+  const bool generic_rows = c->force_generic_dst || !(c->fftN == 64 * 3 || c->fftN == 64 * 6 || c->fftN == 64 * 15);
+  if (c->g.cyc && in_step && !c->no_fused_constr && generic_rows) {
+    // cyclic ocean with generic row sizes (SOcn 5 km), inside qgcm_hip_steps: part A of the constraint algebra rides in
+    // the Thomas launch, part B in the inverse-row launch (it reads ksum and ybnd, not wrk): no launch of its own
+    if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, true)) return 1;
+    if (launch_dst(c, c->wrk, c->g.nl, true, 0, nullptr, true)) return 1;
+    if (launch_unpack(c, fuse_bdy)) return 1;
     c->ip ^= 1;
     return 0;
   }
