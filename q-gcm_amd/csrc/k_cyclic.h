@@ -286,9 +286,10 @@ __device__ __forceinline__ void constr_cyc_partB(const QgCycConstrParams &P, int
 }
 
 // part B alone, reading the new constraint vectors part A left in the scalars (k_rfft_cyc's extra workgroup)
-__device__ void rfft_cyc_constr_partB(const QgCycConstrParams *Q, int lane) {
+__device__ __forceinline__ void rfft_cyc_constr_partB(const QgCycConstrParams *Q, int lane) {
   double c1[QG_MAXL], c2[QG_MAXL], c3, ocs[QG_MAXL], ocn[QG_MAXL];
-  for (int k = 0; k < Q->g.nl; ++k) {
+#pragma unroll
+  for (int k = 0; k < QG_MAXL; ++k) { // (all QG_MAXL slots exist in the scalars; compile-time indices keep them in registers)
     ocs[k] = Q->sc->ocncs[k];
     ocn[k] = Q->sc->ocncn[k];
   }

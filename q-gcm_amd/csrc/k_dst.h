@@ -33,6 +33,7 @@ struct cplx {
 // Stockham stages below are autosort (natural order); the three-stage plans of k_fft3.h are padded and digit-reversed.
 struct FftPlanNatural {
   static constexpr bool three_stage = false;
+  static constexpr int N = 0; // run-time length (QgDstParams.N)
   struct Tw {};
   template <int NT>
   static __device__ __forceinline__ Tw prefetch(const double2 *, int) { return Tw{}; }
@@ -196,7 +197,7 @@ __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict_
 template <bool ROWSUM, int NT = DST_NT, class PLAN = FftPlanNatural>
 __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int N = P.N, n = N - 1;
+  const int N = PLAN::three_stage ? PLAN::N : P.N, n = N - 1; // compile-time for the three-stage plans: loops unroll
   const bool single = PLAN::three_stage || P.single != 0; // one LDS buffer, in-place stages (N even, see DST_SINGLE_*)
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
   cplx *B = single ? A : A + N;
@@ -215,9 +216,12 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   // ---- pre-twiddle (dsint.f:19-33): element a[k], k=1..n lives at index k-1
   const int ns2 = n / 2;
   if (tid == 0) A[0] = {0.0, 0.0};
+  const double *rbp = has_b ? rowb : rowa; // the odd last row has no partner: loads redirected, values zeroed
+  const double bsc = has_b ? 1.0 : 0.0;
+#pragma unroll
   for (int k = 1 + tid; k <= ns2; k += NT) {
     double xa = rowa[k - 1], xac = rowa[n - k];
-    double xb = has_b ? rowb[k - 1] : 0.0, xbc = has_b ? rowb[n - k] : 0.0;
+    double xb = bsc * rbp[k - 1], xbc = bsc * rbp[n - k];
     double sn = P.sintab[k];
     double t1a = xa - xac, t2a = sn * (xa + xac);
     double t1b = xb - xbc, t2b = sn * (xb + xbc);
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   const int k0 = 1 + tid * chunk;
   const double b1a = 0.5 * Z[0].x, b1b = 0.5 * Z[0].y; // read before anything is staged over the spectrum
   double suma = 0.0, sumb = 0.0;
+#pragma unroll
   for (int k = k0; k < k0 + chunk && k <= K; ++k) {
     cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out(N - k)];
     suma += 0.5 * (z1.x + z2.x);
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     rsa += b1a;
     rsb += b1b;
   }
+#pragma unroll
   for (int k = k0; k < k0 + chunk && k <= K; ++k) {
     cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out(N - k)];
     double rea = 0.5 * (z1.x + z2.x), ima = 0.5 * (z1.y - z2.y);
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   }
   __syncthreads();
   if (single) {
+#pragma unroll
     for (int i = tid; i < n; i += NT) {
       const int k = (i + 1) >> 1;
       const cplx za = Z[PLAN::pos_out(k)], zb = Z[PLAN::pos_out((N - k) % N)];
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
 // ---------------------------------------------------------------------------
 #define RFFT_NT 512
 // defined in k_cyclic.h (included after this file): part B of the cyclic constraint algebra by one wave, all layer counts
-__device__ void rfft_cyc_constr_partB(const struct QgCycConstrParams *Q, int lane);
+__device__ __forceinline__ void rfft_cyc_constr_partB(const struct QgCycConstrParams *Q, int lane);
 
 template <bool INV, class PLAN = FftPlanNatural, int NT = RFFT_NT>
 __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
     if (blockIdx.y == 0 && threadIdx.x < 64) rfft_cyc_constr_partB(P.cycq, threadIdx.x);
     return;
   }
-  const int N = P.N, H = N / 2;
+  const int N = PLAN::three_stage ? PLAN::N : P.N, H = N / 2;
   const bool single = PLAN::three_stage || P.single != 0;
   cplx *A = reinterpret_cast<cplx *>(smem_raw);
   cplx *B = single ? A : A + N;
@@ -426,10 +433,53 @@ __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
   double *rowb = rowa + ldw;
   typename PLAN::Tw tw3 = PLAN::template prefetch<NT>(P.twid, tid); // table values requested before the rows
 
+  // With a compile-time length (three-stage plans) the row loops are fully unrolled: all loads of a thread are in
+  // flight together instead of one memory round trip per iteration of a rolled loop.
+  constexpr int NC = PLAN::N;
   if (!INV) {
-    for (int j = tid; j < N; j += NT) A[PLAN::pos_in(j)] = {rowa[j], has_b ? rowb[j] : 0.0};
+    if constexpr (PLAN::three_stage) {
+      double2 v[(NC + NT - 1) / NT];
+#pragma unroll
+      for (int it = 0; it < (NC + NT - 1) / NT; ++it) {
+        const int j = tid + it * NT, jc = j < NC ? j : 0;
+        v[it] = {rowa[jc], has_b ? rowb[jc] : 0.0};
+      }
+#pragma unroll
+      for (int it = 0; it < (NC + NT - 1) / NT; ++it) {
+        const int j = tid + it * NT;
+        if (j < NC) A[PLAN::pos_in(j)] = {v[it].x, v[it].y};
+      }
+    } else {
+      for (int j = tid; j < N; j += NT) A[PLAN::pos_in(j)] = {rowa[j], has_b ? rowb[j] : 0.0};
+    }
   } else {
     // half-complex rows -> conj(Z), Z_k = Xa_k + i Xb_k
+    if constexpr (PLAN::three_stage) {
+      // unconditional loads at clamped indices, all in flight together; the special coefficients k = 0, N/2 by selects
+      constexpr int HC = NC / 2, NIT = (HC + 1 + NT - 1) / NT;
+      double2 va[NIT], vb[NIT];
+      const double *rb = has_b ? rowb : rowa;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = tid + it * NT;
+        const int kc = k <= HC ? k : 0;
+        const int i1 = (kc == 0) ? 0 : (kc == HC ? NC - 1 : 2 * kc - 1), i2 = (kc == 0 || kc == HC) ? i1 : 2 * kc;
+        va[it] = {rowa[i1], rowa[i2]};
+        vb[it] = {rb[i1], rb[i2]};
+      }
+      const double bs = has_b ? 1.0 : 0.0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = tid + it * NT;
+        if (k <= HC) {
+          const bool edge = (k == 0 || k == HC);
+          const double ar = va[it].x, ai = edge ? 0.0 : va[it].y;
+          const double br = bs * vb[it].x, bi = edge ? 0.0 : bs * vb[it].y;
+          A[PLAN::pos_in(k)] = {ar - bi, -(ai + br)};
+          if (!edge) A[PLAN::pos_in(NC - k)] = {ar + bi, -(br - ai)};
+        }
+      }
+    } else
     for (int k = tid; k <= H; k += NT) {
       double ar, ai, br, bi;
       if (k == 0) {
@@ -485,7 +535,8 @@ __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
 
   if (!INV) {
     // Xa_k = (Z_k + conj Z_{N-k})/2, Xb_k = (Z_k - conj Z_{N-k})/(2i)
-    for (int k = tid; k <= H; k += NT) {
+#pragma unroll
+    for (int k = tid; k <= (PLAN::three_stage ? NC / 2 : H); k += NT) {
       cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out((N - k) % N)];
       double ar = 0.5 * (z1.x + z2.x), ai = 0.5 * (z1.y - z2.y);
       double br = 0.5 * (z1.y + z2.y), bi = -0.5 * (z1.x - z2.x);
@@ -502,7 +553,8 @@ __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
     }
   } else {
     double rsa = 0.0, rsb = 0.0;
-    for (int j = tid; j < N; j += NT) {
+#pragma unroll
+    for (int j = tid; j < (PLAN::three_stage ? NC : N); j += NT) {
       cplx z = Z[PLAN::pos_out(j)];
       rowa[j] = z.x;
       rsa += z.x;
