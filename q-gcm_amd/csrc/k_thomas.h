@@ -95,7 +95,8 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // grid: (ceil(nk/16), nlayers)
 #define TH_MSG 3
 #define TH_CST 4
-// CYCA: the grid carries one extra workgroup for part A of the cyclic / atmospheric constraint algebra (a template
+// CYCA: the instantiation of the zonally cyclic geometries: it leaves the zonal-mean solution next to the boundaries in
+// ybnd, and its grid carries one extra workgroup for part A of the cyclic / atmospheric constraint algebra (a template
 // flag, not a run-time test: inlined into the plain instantiation the extra code cost it 11 spilled VGPRs at R = 16)
 template <int R, int PHASE, bool CYCA = false>
 __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const int tid = threadIdx.x;
   if (CYCA && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: part A of the cyclic / atmospheric constraint algebra, one wave
-    if (blockIdx.y == 0 && tid < 64) {
+    if (P.cycq && blockIdx.y == 0 && tid < 64) { // (cycq == nullptr: a stand-alone solve, part A runs in k_constr_cyc)
       double a4[QG_MAXL], b4[QG_MAXL];
       switch (P.g.nl) {
         case 2: constr_cyc_partA<2>(*P.cycq, tid, a4, b4); break;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
       if (kok && r < nr) wbase[off0 + (unsigned)(t * ldw)] = ft * w[t];
     }
   }
-  if (PHASE == 0 && P.ybnd && k == 0) {
+  if (CYCA && PHASE == 0 && P.ybnd && k == 0) { // (cyclic instantiation only: the box kernel has no register to spare)
     // cyclic constraints: the zonal-mean solution next to the two zonal boundaries (rows 2 and nypo-1) goes to a side
     // buffer, so that part B of the constraint algebra does not have to read wrk - which the in-place inverse rows of
     // the generic sizes overwrite - and can ride in that launch

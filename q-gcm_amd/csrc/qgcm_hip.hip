@@ -886,16 +886,19 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
   P.nlayers = nlayers;
   P.layer0 = layer0;
   dim3 grid((g.nk + TH_KW - 1) / TH_KW, nlayers);
-  if (cyc_part_a) { // one extra workgroup: part A of the cyclic / atmospheric constraint algebra
-    if (phase != 0 || !c->d_cycq) QG_FAIL("k_thomas: part A of the constraint algebra needs the homogeneous solutions");
-    P.cycq = c->d_cycq;
+  // zonally cyclic geometries use the CYCA instantiation for the whole-column solve: it fills ybnd, and its extra
+  // workgroup runs part A of the constraint algebra when asked to (inside qgcm_hip_steps)
+  const bool cyca = (phase == 0 && g.cyc);
+  if (cyc_part_a && (phase != 0 || !c->d_cycq)) QG_FAIL("k_thomas: part A of the constraint algebra needs the homogeneous solutions");
+  if (cyca) {
+    P.cycq = cyc_part_a ? c->d_cycq : nullptr;
     grid.x += 1;
   }
   KTimer t(c, KN_THOMAS, st);
 #define QG_TH(RV)                                                                                    \
   switch (phase) {                                                                                   \
     case 0:                                                                                          \
-      if (cyc_part_a) hipLaunchKernelGGL((k_thomas<RV, 0, true>), grid, dim3(TH_NT), 0, st, P);      \
+      if (cyca) hipLaunchKernelGGL((k_thomas<RV, 0, true>), grid, dim3(TH_NT), 0, st, P);            \
       else hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, st, P);                       \
       break;                                                                                         \
     case 1: hipLaunchKernelGGL((k_thomas<RV, 1>), grid, dim3(TH_NT), 0, st, P); break;        \
