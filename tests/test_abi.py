@@ -54,3 +54,31 @@ def test_create_fails_loudly_without_gpu():
     from qgcm_hip import OceanModel, QgcmHipError, preset
     with pytest.raises(QgcmHipError):
         OceanModel(preset("box_tiny"))
+
+
+def test_hot_kernels_do_not_spill(repo_root):
+    """The compiler's resource report written next to the library at build time (q-gcm_amd/csrc/Makefile): the kernels
+    of the 5 km step, of SOcn 5 km and of the atmospheric channel use no scratch.  k_thomas<16,0> sits at its 128-VGPR
+    limit (1024-thread workgroups) and has been pushed into scratch by innocent-looking edits more than once - at 5 km
+    that is +13 MB of traffic per launch and a visibly slower step."""
+    path = os.path.join(repo_root, "q-gcm_amd", "lib", "kernel_resources.txt")
+    if not os.path.exists(path):
+        pytest.fail("kernel_resources.txt missing - rebuild with `make -C q-gcm_amd/csrc`")
+    res, cur = {}, None
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and cur:
+            res[cur] = int(m.group(1))
+    hot = ["_Z6k_tendILi3ELb0EEv", "_Z6k_tendILi3ELb1EEv", "_Z7k_dst64ILi15ELb0EEv", "_Z8k_thomasILi16ELi0ELb0EEv",
+           "_Z8k_thomasILi10ELi0ELb1EEv", "_Z8k_thomasILi2ELi0ELb1EEv", "_Z14k_dst64_unpackILi15ELi3ELb1ELb0ELb1EEv",
+           "_Z8k_rfft64ILi6ELb0EEv", "_Z15k_rfft64_unpackILi6ELi3ELb1ELb1EEv", "_Z10k_rfft_cycILb0E8Fft3PlanILi16ELi16ELi18EELi256EEv",
+           "_Z10k_rfft_cycILb1E8Fft3PlanILi16ELi16ELi18EELi256EEv", "_Z9k_dst_boxILb0ELi256E8Fft3PlanILi15ELi16ELi20EEEv",
+           "_Z10k_oml_step11QgOmlParams", "_Z11k_oml_entoc11QgOmlParams"]
+    for h in hot:
+        hits = [k for k in res if k.startswith(h)]
+        assert hits, "kernel %s not in the report" % h
+        for k in hits:
+            assert res[k] == 0, "%s spills %d B per lane" % (k, res[k])
