@@ -35,7 +35,7 @@
 #define TH_KW 16   // wavenumbers per workgroup (128-B line)
 #define TH_NC 64   // chunks per column
 #define TH_NT (TH_KW * TH_NC)
-static_assert(TH_NC == 64 && TH_KW == 16, "the chunk scan maps 64 chunks to the lanes of 16 waves");
+static_assert(TH_NC == 64, "the chunk scan maps the 64 chunks of a wavenumber to the lanes of one wave");
 
 // Inclusive scan of affine maps over the 64 lanes of a wave (lane = position in
 // sweep order).  On return (Cs, Ds) is the composition of positions 0..lane.
@@ -98,14 +98,18 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // CYCA: the instantiation of the zonally cyclic geometries: it leaves the zonal-mean solution next to the boundaries in
 // ybnd, and its grid carries one extra workgroup for part A of the cyclic / atmospheric constraint algebra (a template
 // flag, not a run-time test: inlined into the plain instantiation the extra code cost it 11 spilled VGPRs at R = 16)
-template <int R, int PHASE, bool CYCA = false>
-__global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
+// KW: wavenumbers per workgroup = waves per workgroup.  16 (a 128-byte line per row, 1024 threads, 128 VGPRs) up to
+// 16 rows per thread; 8 (512 threads, 256 VGPRs) for the long columns - R >= 20 keeps 4R doubles of rows and pivots in
+// registers and spilled 100-800 B per lane under the 128-VGPR limit.
+template <int R, int PHASE, bool CYCA = false, int KW = TH_KW>
+__global__ __launch_bounds__(KW * TH_NC) void k_thomas(const QgThomasParams P) {
+  static_assert(TH_KW % KW == 0, "a workgroup's wavenumbers lie inside one block of the pivot tables");
   // pitch TH_KW + 1: the scans read / write these arrays transposed ([lane][wv]: 64 lanes at a stride of one row);
   // at a pitch of 16 doubles = 128 B every lane hit the same pair of banks (SQ_LDS_BANK_CONFLICT was 55 % of the
   // kernel's LDS cycles)
-  __shared__ double sC[TH_NC][TH_KW + 1];
-  __shared__ double sD[TH_NC][TH_KW + 1];
-  __shared__ double sIn[TH_NC][TH_KW + 1];
+  __shared__ double sC[TH_NC][KW + 1];
+  __shared__ double sD[TH_NC][KW + 1];
+  __shared__ double sIn[TH_NC][KW + 1];
   const int tid = threadIdx.x;
   if (CYCA && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: part A of the cyclic / atmospheric constraint algebra, one wave
@@ -119,11 +123,11 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
     }
     return;
   }
-  const int kk = tid % TH_KW;
-  const int c = tid / TH_KW;
+  const int kk = tid % KW;
+  const int c = tid / KW;
   const int lane = tid & 63, wv = tid >> 6;
-  const int k = blockIdx.x * TH_KW + kk;
-  const int kq = blockIdx.x * TH_KW + wv; // wavenumber whose chunk maps this wave scans
+  const int k = blockIdx.x * KW + kk;
+  const int kq = blockIdx.x * KW + wv; // wavenumber whose chunk maps this wave scans
   const int m = blockIdx.y + P.layer0;
   const int nr = P.g.jr1 - P.g.jr0 + 1; // local rows jr0..jr1  <->  r = 0..nr-1
   const int ldw = P.g.ldw;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   const double ft = P.ftnorm;
 
   // 32-bit element offsets from a uniform base (one scalar pointer + one VGPR per address)
-  const double *wbase_c = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + blockIdx.x * TH_KW;
+  const double *wbase_c = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + blockIdx.x * KW;
   double *wbase = const_cast<double *>(wbase_c);
   const unsigned off0 = (unsigned)(r0 * ldw + kk);
   // rows past the end of the slab: PHASE 0 (whole column, zero inflow at both ends) pads them with w = 0, b = 0 - the
@@ -152,13 +156,13 @@ __global__ __launch_bounds__(TH_NT) void k_thomas(const QgThomasParams P) {
   // pivots of this chunk (src/ocisubs.F:472-477, tabulated by the host): rows below rcb from the block's table,
   // the stationary value after that
   {
-    const int tb = m * P.nblk + blockIdx.x;
+    const int tb = m * P.nblk + (blockIdx.x * KW) / TH_KW; // the tables are per block of TH_KW wavenumbers
     const int rcb = P.rcb[tb];
     const double binf = kok ? P.binf[(long)m * ldw + k] : 0.0;
 #pragma unroll
     for (int t = 0; t < R; ++t) b[t] = binf;
     if (r0 < rcb) {
-      const double *tab = P.ptab + (long)P.poff[tb] * TH_KW + kk;
+      const double *tab = P.ptab + (long)P.poff[tb] * TH_KW + (blockIdx.x * KW) % TH_KW + kk;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         const int r = r0 + t;

@@ -885,38 +885,37 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
   P.ftnorm = g.cyc ? 1.0 / g.nxt : 0.5 / g.nxt; // src/ocisubs.F:440, 547
   P.nlayers = nlayers;
   P.layer0 = layer0;
-  dim3 grid((g.nk + TH_KW - 1) / TH_KW, nlayers);
   // zonally cyclic geometries use the CYCA instantiation for the whole-column solve: it fills ybnd, and its extra
   // workgroup runs part A of the constraint algebra when asked to (inside qgcm_hip_steps)
   const bool cyca = (phase == 0 && g.cyc);
   if (cyc_part_a && (phase != 0 || !c->d_cycq)) QG_FAIL("k_thomas: part A of the constraint algebra needs the homogeneous solutions");
-  if (cyca) {
-    P.cycq = cyc_part_a ? c->d_cycq : nullptr;
-    grid.x += 1;
-  }
+  if (cyca) P.cycq = cyc_part_a ? c->d_cycq : nullptr; // (its extra workgroup is added to the grid below)
   KTimer t(c, KN_THOMAS, st);
-#define QG_TH(RV)                                                                                    \
-  switch (phase) {                                                                                   \
-    case 0:                                                                                          \
-      if (cyca) hipLaunchKernelGGL((k_thomas<RV, 0, true>), grid, dim3(TH_NT), 0, st, P);            \
-      else hipLaunchKernelGGL((k_thomas<RV, 0>), grid, dim3(TH_NT), 0, st, P);                       \
-      break;                                                                                         \
-    case 1: hipLaunchKernelGGL((k_thomas<RV, 1>), grid, dim3(TH_NT), 0, st, P); break;        \
-    case 2: hipLaunchKernelGGL((k_thomas<RV, 2>), grid, dim3(TH_NT), 0, st, P); break;        \
-    case 4: hipLaunchKernelGGL((k_thomas<RV, 4>), grid, dim3(TH_NT), 0, st, P); break;        \
-    default: hipLaunchKernelGGL((k_thomas<RV, 5>), grid, dim3(TH_NT), 0, st, P); break;       \
+#define QG_TH(RV, KWV)                                                                                                  \
+  {                                                                                                                      \
+    dim3 gridk((g.nk + KWV - 1) / KWV + (cyca ? 1 : 0), nlayers);                                                        \
+    switch (phase) {                                                                                                     \
+      case 0:                                                                                                            \
+        if (cyca) hipLaunchKernelGGL((k_thomas<RV, 0, true, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P);                  \
+        else hipLaunchKernelGGL((k_thomas<RV, 0, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P);                      \
+        break;                                                                                                           \
+      case 1: hipLaunchKernelGGL((k_thomas<RV, 1, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;              \
+      case 2: hipLaunchKernelGGL((k_thomas<RV, 2, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;              \
+      case 4: hipLaunchKernelGGL((k_thomas<RV, 4, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;              \
+      default: hipLaunchKernelGGL((k_thomas<RV, 5, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;             \
+    }                                                                                                                    \
   }
   switch (c->thR) {
-    case 1: QG_TH(1); break;
-    case 2: QG_TH(2); break;
-    case 4: QG_TH(4); break;
-    case 8: QG_TH(8); break;
-    case 10: QG_TH(10); break;
-    case 12: QG_TH(12); break;
-    case 16: QG_TH(16); break;
-    case 20: QG_TH(20); break;
-    case 24: QG_TH(24); break;
-    case 32: QG_TH(32); break;
+    case 1: QG_TH(1, 16); break;
+    case 2: QG_TH(2, 16); break;
+    case 4: QG_TH(4, 16); break;
+    case 8: QG_TH(8, 16); break;
+    case 10: QG_TH(10, 16); break;
+    case 12: QG_TH(12, 16); break;
+    case 16: QG_TH(16, 16); break;
+    case 20: QG_TH(20, 8); break; // long columns: 512-thread workgroups, 256 VGPRs (k_thomas.h)
+    case 24: QG_TH(24, 8); break;
+    case 32: QG_TH(32, 8); break;
     default: QG_FAIL("k_thomas: too many rows for the single-segment kernel");
   }
 #undef QG_TH

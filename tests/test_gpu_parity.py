@@ -342,6 +342,62 @@ def test_long_row_transform_sizes(nxto, cyclic):
         o.close()
 
 
+@pytest.mark.parametrize("nyaooc,nranks", [(100, 1), (160, 1), (200, 2)])
+def test_long_columns(nyaooc, nranks):
+    """Columns of 1025..2048 interior rows per handle keep 20 / 24 / 32 rows per thread in the tridiagonal kernel: those
+    instantiations run 512-thread workgroups of 8 wavenumbers (256 VGPRs; with 1024 threads they spilled 100-800 B per
+    lane).  A tall thin basin, 49 x (12*nyaooc+1) x 3: the Helmholtz solver and 12 steps against the oracle; the tallest
+    also as two y-slabs (1201 rows each: the summary phases at 20 rows per thread)."""
+    import torch
+    from qgcm_hip import OceanModel, hostinit, synth
+    from qgcm_hip.config import OceanConfig
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = OceanConfig("tall_%d" % nyaooc, 8, nyaooc + 4, 4, nyaooc, 12, 3, dxo=1.0e5, dta=720.0, ah4oc=(3.2e12,) * 3,
+                      fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
+    assert cfg.nxto == 48 and cfg.nypo == 12 * nyaooc + 1
+    o = make_oracle(cfg)
+    slabs = []
+    m = OceanModel(cfg) if nranks == 1 else None
+    try:
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        zero2, xon = np.zeros_like(wek), np.zeros(cfg.nlo - 1)
+        o.set_p(po, po)
+        o.set_forcing(wek, zero2, xon)
+        if nranks == 1:
+            rng = np.random.default_rng(nyaooc)
+            rhs = np.asfortranarray(rng.standard_normal((cfg.nxpo, cfg.nypo)))
+            boc = m.bd2oc - m.rdm2oc[1]
+            assert relerr(m.helmholtz(rhs, boc), o.helmholtz(rhs, boc)) < TOL_CALL
+            m.set_p(po, po)
+            m.set_forcing(wek, zero2, xon)
+            m.steps(12, s0=1)
+            got = m.get_state()
+        else:
+            consts = global_consts(cfg, o.helmholtz)
+            qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+            scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+            parts = partition(cfg.nypo, nranks)
+            slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+            so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+            so.scatter_state(po, po, qo, qo, wek, zero2, xon, scal)
+            so.steps(12, s0=1)
+            got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+            for g0, g1, fields in so.gather_local():
+                for dst, src in zip(got, fields):
+                    dst[:, g0 - 1:g1, :] = src
+        o.steps(1, 12)
+        for f, x, y in zip(FIELDS, got, o.get_state()):
+            assert relerr(x, y) < 1e-10, (f, nyaooc)
+    finally:
+        for sl in slabs:
+            sl.close()
+        if m is not None:
+            m.close()
+        o.close()
+
+
 def test_fused_inverse_transform_unpack_bitwise():
     """k_dst64_unpack (inverse row transform + modes -> layers + boundary PV in one launch) against
     the separate k_dst64 / k_unpack_box (/ k_ocqbdy) launches: same expressions, so bitwise equal --
