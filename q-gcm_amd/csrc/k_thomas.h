@@ -14,8 +14,12 @@
 // block made that workgroup - and with it the launch - 4 us longer than the rest.)
 //
 // Parallel formulation: both sweeps are first-order linear recurrences
-//     forward : u_r = (w_r - aoc*u_{r-1}) * bet_r
-//     backward: v_r = u_r - aoc*bet_r * v_{r+1}
+//     forward : u_r = (w_r - aoc*u_{r-1}) * bet_r     = fma(-g_r, u_{r-1}, w_r*bet_r),  g_r = aoc*bet_r
+//     backward: v_r = u_r - aoc*bet_r * v_{r+1}       = fma(-g_r, v_{r+1}, u_r)
+// (one fused multiply-add per row and sweep: the chain of dependent operations per row is 1 instead of 3, 16 -> 10
+// VALU instructions per row in all, and with w*bet and g held in place of w and bet the kernel needs 92 VGPRs
+// instead of 124.  The reference's rounding sequence is not kept - no chunked evaluation can keep it - the
+// difference stays at the rounding level: tests/test_gpu_parity.py compares with the reference at 1e-12.)
 // The rows are cut into 64 chunks of R rows; lanes hold 16 consecutive
 // wavenumbers (one 128-B line) x 4 chunks per wave, a workgroup of 1024
 // threads covers a whole column block.  Each thread keeps its R rows in
@@ -219,9 +223,14 @@ __global__ __launch_bounds__(KW * TH_NC) void k_thomas(const QgThomasParams P) {
   double C = 0.0, D = 1.0;
 #pragma unroll
   for (int t = 0; t < R; ++t) {
+    w[t] *= b[t];
+    b[t] *= a;
+  }
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
     if (!PRED || r0 + t < nr) {
-      C = (w[t] - a * C) * b[t];
-      D = -(a * b[t]) * D;
+      C = __builtin_fma(-b[t], C, w[t]);
+      D = -b[t] * D;
     }
   }
   sC[c][kk] = C;
@@ -241,20 +250,18 @@ __global__ __launch_bounds__(KW * TH_NC) void k_thomas(const QgThomasParams P) {
 #pragma unroll
   for (int t = 0; t < R; ++t) {
     if (!PRED || r0 + t < nr) {
-      u = (w[t] - a * u) * b[t];
+      u = __builtin_fma(-b[t], u, w[t]);
       w[t] = u;
     }
-    b[t] = a * b[t]; // the backward sweep only needs a*bet
   }
   // ---- backward: v_r = u_r - a*bet_r*v_{r+1} ------------------------------
-  // (the chunk gain is formed again, in descending order; reusing the forward product would save R multiplies and
-  // change the rounding of the composed inflows)
+  // (the chunk gain is formed again, in descending order)
   C = 0.0;
   D = 1.0;
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
     if (!PRED || r0 + t < nr) {
-      C = w[t] - b[t] * C;
+      C = __builtin_fma(-b[t], C, w[t]);
       D = -b[t] * D;
     }
   }
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(KW * TH_NC) void k_thomas(const QgThomasParams P) {
 #pragma unroll
   for (int t = R - 1; t >= 0; --t) {
     if (!PRED || r0 + t < nr) {
-      v = w[t] - b[t] * v;
+      v = __builtin_fma(-b[t], v, w[t]);
       w[t] = v;
       colsum += v;
     }
