@@ -194,9 +194,23 @@ __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict_
 // grid: (ceil(nrows/2), nlayers);  rows j = jr0..jr1 (owned, interior to the global domain)
 // dynamic LDS: 2*N cplx + 2*NT doubles; NT = 128 threads for short rows, DST_NT_BIG for long ones (a long row
 // fills the LDS of a CU by itself, so the one resident workgroup must bring enough waves)
+template <int NL>
+__device__ __forceinline__ void constr_box_all(const QgConstrParams &P, int lane); // k_misc.h
+
 template <bool ROWSUM, int NT = DST_NT, class PLAN = FftPlanNatural>
 __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  if (P.boxq && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup of the inverse rows inside a step: the box constraint solve (one wave; nothing of it
+    // depends on the rows, the unpack launch that follows reads its coefficients)
+    if (blockIdx.y == 0 && threadIdx.x < 64) {
+      switch (P.g.nl) {
+        case 2: constr_box_all<2>(*P.boxq, threadIdx.x); break;
+        default: constr_box_all<3>(*P.boxq, threadIdx.x); break; // (4 layers: the pivot search indexes at run time -
+      }                                                          //  scratch; such oceans keep the k_constr_box launch)
+    }
+    return;
+  }
   const int N = PLAN::three_stage ? PLAN::N : P.N, n = N - 1; // compile-time for the three-stage plans: loops unroll
   const bool single = PLAN::three_stage || P.single != 0; // one LDS buffer, in-place stages (N even, see DST_SINGLE_*)
   cplx *A = reinterpret_cast<cplx *>(smem_raw);

@@ -177,8 +177,7 @@ __global__ __launch_bounds__(256) void k_fill_rows(double *w, long wstride, int 
 // latency-bound kernel several times slower).  Inside qgcm_hip_steps the box ocean does without this launch:
 // the same functions run in k_tend (dpioc update) and in every workgroup of k_dst64_unpack<.., CONSTR>.
 template <int NL>
-__global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void constr_box_all(const QgConstrParams &P, int lane) {
   constexpr int n1 = NL - 1;
   double xin[NL];
   constr_xin<NL>(P, lane, xin);
@@ -193,6 +192,12 @@ __global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
   constr_box_solve<NL>(P, xin, dpn, x);
 #pragma unroll
   for (int k = 0; k < n1; ++k) sc->hclco[k] = x[k];
+}
+
+// (rows of other sizes than 64*M: the same body rides as one extra workgroup of the inverse-row launch, k_dst_box)
+template <int NL>
+__global__ __launch_bounds__(64) void k_constr_box(const QgConstrParams P) {
+  constr_box_all<NL>(P, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------

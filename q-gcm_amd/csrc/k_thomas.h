@@ -106,7 +106,10 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // 16 rows per thread; 8 (512 threads, 256 VGPRs) for the long columns - R >= 20 keeps 4R doubles of rows and pivots in
 // registers and spilled 100-800 B per lane under the 128-VGPR limit.
 template <int R, int PHASE, bool CYCA = false, int KW = TH_KW>
-__global__ __launch_bounds__(KW * TH_NC) void k_thomas(const QgThomasParams P) {
+// (second launch bound = waves per SIMD.  The summary phase of a y-slab neither stores rows nor keeps them for the
+// backward sweep: with <= 10 rows per thread it fits 64 VGPRs, two workgroups share a CU and the launches of many
+// generations - NAtl 1 km: 900 workgroups - gain a quarter: 29 -> 21 us.  PHASE 2 at 64 VGPRs spills: 50 -> 70 us.)
+__global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8 : 1) void k_thomas(const QgThomasParams P) {
   static_assert(TH_KW % KW == 0, "a workgroup's wavenumbers lie inside one block of the pivot tables");
   // pitch TH_KW + 1: the scans read / write these arrays transposed ([lane][wv]: 64 lanes at a stride of one row);
   // at a pitch of 16 doubles = 128 B every lane hit the same pair of banks (SQ_LDS_BANK_CONFLICT was 55 % of the

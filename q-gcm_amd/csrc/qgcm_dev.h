@@ -86,6 +86,9 @@ struct QgDstParams {
   // generic cyclic inverse rows inside qgcm_hip_steps: one extra workgroup (blockIdx.x == gridDim.x - 1) runs part B of
   // the constraint algebra (k_cyclic.h) instead of a launch of its own; nullptr otherwise
   const struct QgCycConstrParams *cycq;
+  // generic box inverse rows: one extra workgroup (blockIdx.x == gridDim.x - 1) runs the box constraint solve
+  // (k_constr_box's body, k_misc.h) instead of a launch of its own; nullptr otherwise
+  const struct QgConstrParams *boxq;
 };
 
 struct QgThomasParams {

@@ -73,6 +73,7 @@ struct qgcm_hip_ctx {
   int th_cgath_ranks = 0;
   double *ksum, *wcot;                     // spectral column sums of the solution and their cot weights (k_thomas.h)
   double *bpart;                           // cyclic: partial boundary line sums (k_tend's extra workgroups -> constraint algebra)
+  QgConstrParams *d_boxq = nullptr;        // box: device copy of the constraint parameters (generic inverse rows' extra workgroup)
   QgCycConstrParams *d_cycq = nullptr;     // cyclic: device copy of the constraint parameters (fused step path)
   int thR;                                 // rows per chunk of the Thomas kernel
   double *pch1, *pch2, *pbh;
@@ -293,6 +294,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   if (c->twid) hipFree(c->twid);
   hipFree(c->sc);
   if (c->d_cycq) hipFree(c->d_cycq);
+  if (c->d_boxq) hipFree(c->d_boxq);
   for (QgThomasTab *t : {&c->tt, &c->tt_tmp}) {
     if (t->binf) hipFree(t->binf);
     if (t->ptab) hipFree(t->ptab);
@@ -518,6 +520,8 @@ static int lu_factor(int n, double *a, int *piv) {
   return 0;
 }
 
+static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P);
+
 extern "C" int qgcm_hip_set_homog_box(qgcm_hip_handle c, const double *ochom, const double *cdiffo, const double *cdhoc) {
   if (!c || !ochom || !cdiffo || !cdhoc) QG_FAIL("qgcm_hip_set_homog_box: null argument");
   if (c->g.cyc) QG_FAIL("qgcm_hip_set_homog_box: handle is cyclic");
@@ -531,6 +535,13 @@ extern "C" int qgcm_hip_set_homog_box(qgcm_hip_handle c, const double *ochom, co
   int info = lu_factor(n1, c->cs.cdhlu, c->cs.ipiv); // DGETRF, src/conhoms.F:627
   if (info) QG_FAIL("qgcm_hip_set_homog_box: cdhoc is singular (info=%d)", info);
   c->homog_set = true;
+  {
+    // device copy of the constraint parameters for the extra workgroup of the generic inverse rows
+    QgConstrParams Q;
+    fill_constr_params(c, Q);
+    if (!c->d_boxq) HIPCHECK(hipMalloc((void **)&c->d_boxq, sizeof(Q)));
+    HIPCHECK(hipMemcpy(c->d_boxq, &Q, sizeof(Q), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -787,8 +798,15 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   return 0;
 }
 
+// box rows that run k_dst_box (not the wave-per-row-pair kernels of k_dst64.h)
+static bool dst_box_generic(const qgcm_hip_ctx *c) {
+  return !c->g.cyc && (c->force_generic_dst || !(c->fftN == 64 * 15 || c->fftN == 64 * 3));
+}
+// ... whose inverse launch can carry the box constraint solve as an extra workgroup (2 or 3 layers, see k_dst_box)
+static bool dst_box_rides_constr(const qgcm_hip_ctx *c) { return dst_box_generic(c) && c->g.nl <= 3 && !c->no_fused_constr; }
+
 static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, int layer0 = 0, hipStream_t st = nullptr,
-                      bool cyc_part_b = false) {
+                      bool cyc_part_b = false, bool box_constr = false) {
   if (!st) st = c->stream;
   const QgGeom &g = c->g;
   QgDstParams P;
@@ -811,6 +829,11 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   if (cyc_part_b) { // generic cyclic inverse rows: one extra workgroup runs part B of the constraint algebra
     if (!inverse || !g.cyc || !c->d_cycq) QG_FAIL("launch_dst: part B rides in the inverse rows of a cyclic ocean with homogeneous solutions");
     P.cycq = c->d_cycq;
+    grid.x += 1;
+  }
+  if (box_constr) { // generic box inverse rows: one extra workgroup runs the constraint solve (k_constr_box's body)
+    if (!inverse || g.cyc || !c->d_boxq || !dst_box_generic(c) || g.nl > 3) QG_FAIL("launch_dst: the box constraint solve rides in the generic inverse rows of a box ocean with homogeneous solutions");
+    P.boxq = c->d_boxq;
     grid.x += 1;
   }
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
@@ -1237,14 +1260,16 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
   }
   if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
   const bool fused_constr = in_step && fuse_bdy && can_fuse_dst_unpack(c) && !c->no_fused_constr;
+  // generic box rows: the constraint solve rides as an extra workgroup of the inverse-row launch
+  const bool ride_constr = !fused_constr && dst_box_rides_constr(c);
   // area (and, cyclic, line) integrals are a by-product of the y sweeps: the constraints precede the inverse transform
-  if (!fused_constr && launch_constr(c)) return 1;
+  if (!fused_constr && !ride_constr && launch_constr(c)) return 1;
   if (can_fuse_dst_unpack(c)) {
     if (launch_dst_unpack(c, fuse_bdy, nullptr, nullptr, fused_constr)) return 1;
     c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
     return 0;
   }
-  if (launch_dst(c, c->wrk, c->g.nl, true)) return 1;
+  if (launch_dst(c, c->wrk, c->g.nl, true, 0, nullptr, false, ride_constr)) return 1;
   if (launch_unpack(c, fuse_bdy)) return 1;
   c->ip ^= 1; // new po sits in the old pom buffer; the old po is pom
   return 0;
@@ -2079,8 +2104,12 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
         c->ip ^= 1;
         return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);
       }
-      if (qgcm_hip_constr(c)) return 1;
-      if (qgcm_hip_row_transform(c, 1)) return 1;
+      if (dst_box_rides_constr(c)) { // box: the constraint solve rides in the inverse-row launch
+        if (launch_dst(c, c->wrk, c->g.nl, true, 0, nullptr, false, true)) return 1;
+      } else {
+        if (qgcm_hip_constr(c)) return 1;
+        if (qgcm_hip_row_transform(c, 1)) return 1;
+      }
       if (qgcm_hip_unpack(c, 1)) return 1;
       if (nranks > 1 && qgcm_hip_halo_pack(c, b, cc)) return 1;
       return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);

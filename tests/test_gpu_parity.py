@@ -156,6 +156,81 @@ def test_random_state_vs_oracle(case):
         o.close()
 
 
+@pytest.mark.parametrize("nlo", [2, 3, 4])
+def test_box_constraint_solve_rides_in_generic_inverse_rows(nlo, monkeypatch):
+    """Box oceans whose rows are not 64*M long run k_dst_box; with 2 or 3 layers the constraint solve (k_constr_box's
+    body) rides as one extra workgroup of the inverse-row launch instead of a launch of its own (4 layers keep the
+    launch).  Same state and scalars, bit for bit, as a handle created with QGCM_HIP_NO_FUSED_CONSTR=1 (stand-alone
+    launch), whole path and two y-slabs; and the oracle's trajectory."""
+    import torch
+    from qgcm_hip import OceanModel, synth
+    from qgcm_hip.config import OceanConfig
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    lay = {2: dict(hoc=(500.0, 3500.0), gpoc=(0.02,), ah2oc=(0.0, 0.0), ah4oc=(1.2e10,) * 2),
+           3: dict(hoc=(350.0, 750.0, 2900.0), gpoc=(0.025, 0.0125), ah2oc=(0.0,) * 3, ah4oc=(1.2e10,) * 3),
+           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4)}[nlo]
+    cfg = OceanConfig("ride_nl%d" % nlo, 10, 8, 10, 6, 16, nlo, dxo=2.5e4, dta=240.0, fnot=9.37456e-05, beta=1.7536e-11,
+                      cyclic=False, **lay)
+    assert cfg.nxto % 64 != 0
+    po = synth.gaussian_eddy(cfg, noise=2e-2, seed=5)
+    pom = np.asfortranarray(0.99 * po)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    ent = np.zeros_like(wek)
+    xon = np.zeros(nlo - 1)
+    xon[0] = 2e2
+
+    nconstr = []
+
+    def run(whole_only=False):
+        m = OceanModel(cfg)
+        slabs = []
+        try:
+            m.set_p(po, pom)
+            m.set_forcing(wek, ent, xon)
+            st0, scal0 = m.get_state(), m.get_scalars()
+            m.steps(30, s0=1)
+            out = [m.get_state(), m.get_scalars()]
+            prof = m.profile_steps(4, s0=31)  # (after the state was taken) launches per kernel of four eager steps
+            nconstr.append(prof.get("k_constr", (0.0, 0))[1])
+            if not whole_only:
+                consts = global_consts(cfg)
+                parts = partition(cfg.nypo, 2)
+                slabs = [HipSlab(cfg, consts, g0, g1, r, 2, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+                so = SlabOcean(cfg, slabs, LocalComm(2, after=torch.cuda.synchronize))
+                so.homsol()
+                so.scatter_state(st0[0], st0[1], st0[2], st0[3], wek, ent, xon, scal0)
+                so.steps(30, s0=1)
+                out.append([f.copy() for _, _, fs in so.gather_local() for f in fs])
+                out.append(slabs[0].get_scalars())
+            return out
+        finally:
+            m.close()
+            for sl in slabs:
+                sl.close()
+
+    ride = run()
+    monkeypatch.setenv("QGCM_HIP_NO_FUSED_CONSTR", "1")  # read when a handle is created
+    launch = run()
+    monkeypatch.delenv("QGCM_HIP_NO_FUSED_CONSTR")
+    assert nconstr == [0 if nlo <= 3 else 4, 4], nconstr  # no launch of its own when it rides
+    for x, y in zip(ride[0], launch[0]):
+        assert np.array_equal(x, y), nlo
+    assert np.array_equal(ride[1], launch[1])
+    for x, y in zip(ride[2], launch[2]):
+        assert np.array_equal(x, y), nlo
+    assert np.array_equal(ride[3], launch[3])
+    o = make_oracle(cfg)
+    try:
+        o.set_p(po, pom)
+        o.set_forcing(wek, ent, xon)
+        o.steps(1, 30)
+        for f, x, y in zip(FIELDS, ride[0], o.get_state()):
+            assert relerr(x, y) < 1e-10, (f, nlo)
+    finally:
+        o.close()
+
+
 @pytest.mark.parametrize("nlo,cyclic", [(2, False), (4, False), (2, True), (4, True)])
 def test_fast_kernels_with_two_and_four_layers(nlo, cyclic):
     """The wave-per-row-pair kernels (nxto = 192 = 64*3) and their fused inverse-transform / unpack / constraint-wave
