@@ -42,7 +42,12 @@ struct FftPlanNatural {
 };
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
+// (the row transforms are not required to be bitwise FFTPACK: the complex product is two multiplies and two fused
+// multiply-adds, contracted by the front end - the same in every kernel it is inlined into - while the rest of the
+// library stays at -ffp-contract=off)
+#pragma clang fp contract(on)
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+#pragma clang fp contract(off)
 // multiply by -i (forward quarter turn)
 __device__ __forceinline__ cplx cmni(cplx a) { return {a.y, -a.x}; }
 
