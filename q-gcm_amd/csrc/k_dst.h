@@ -51,6 +51,10 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y *
 // multiply by -i (forward quarter turn)
 __device__ __forceinline__ cplx cmni(cplx a) { return {a.y, -a.x}; }
 
+// Everything below is row-transform arithmetic (pre-twiddle, FFT stages, spectrum split, running-sum post-process):
+// fused multiply-adds allowed, as in k_dst64.h / k_fft3.h / k_rfft64.h.
+#pragma clang fp contract(fast)
+
 // forward 8-point DFT, y[c] = sum_a x[a] exp(-2 pi i a c / 8), in place (radix-8 stage of the generic plan)
 __device__ __forceinline__ void dft8_g(cplx *x) {
   const double r2 = 0.70710678118654752440;
@@ -607,3 +611,5 @@ __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
     }
   }
 }
+
+#pragma clang fp contract(off)
