@@ -193,7 +193,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p, nsteps, nwarm, bid, with_oml=False):
+def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p, nsteps, nwarm, bid, with_oml=False, overlap=False):
     """A secondary multi-GPU figure: the basin `cfg` cut into `world` y-slabs, one per rank, stepped by the driver
     the headline measurement settled on (library-issued RCCL exchanges if they were verified there, else
     torch.distributed).  Returns basin steps/s etc. (max over ranks); every rank must call it (collective)."""
@@ -225,6 +225,7 @@ def slab_secondary(cfg, world, rank, local_rank, barrier, use_library, halo_p2p,
     if use_library:
         so.use_library_exchanges(broadcast_unique_id(dist, slab.device))
         slab.set_halo_p2p(halo_p2p)
+        slab.set_overlap(overlap)  # (the choice of the headline measurement; never applies with the mixed layer on)
         driver = "library-issued RCCL (qgcm_hip_slab_steps)"
     driver += ", halo rows by %s" % ("send/recv" if halo_p2p else "all-gather")
     so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
@@ -380,8 +381,9 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
 
             # transport of the halo rows: one all-gather of everybody's edge rows, or grouped send/recv with the
             # two neighbours - measured on this node (max over ranks), the faster one is used if it is also bitwise
-            def timed(p2p):
+            def timed(p2p, overlap=False):
                 slab.set_halo_p2p(p2p)
+                slab.set_overlap(overlap)
                 so.scatter_state(po, po, qo, qo, wek, zero2, xon0, scal)
                 so.steps(nver, s0=1)
                 same = all(np.array_equal(a, b) for a, b in zip(ref, local_state()))
@@ -400,9 +402,20 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
                 slab.set_halo_p2p(use_p2p)
                 driver += "; halo rows by %s (all-gather %.1f us/step, send/recv %.1f us/step%s)" % (
                     "send/recv" if use_p2p else "all-gather", 1e4 * t_ag, 1e4 * t_pp, "" if ok_pp else ", send/recv NOT bitwise")
+                # the halo exchange on a second stream under the inner tile rows of the next step's tendency launch
+                # (qgcm_hip_comm_set_overlap): kept if bitwise and faster on this node
+                t_base = t_pp if use_p2p else t_ag
+                t_ov, ok_ov = timed(use_p2p, True)
+                use_ov = ok_ov and t_ov < t_base
+                slab.set_overlap(use_ov)
+                extra["halo_overlap"] = {"used": bool(use_ov), "bitwise": bool(ok_ov), "us_per_step_plain": round(1e4 * t_base, 2),
+                                         "us_per_step_overlapped": round(1e4 * t_ov, 2)}
+                driver += "; halo exchange %s the next step's inner tendency tiles (%.1f vs %.1f us/step)" % (
+                    "overlapped with" if use_ov else "NOT overlapped with", 1e4 * t_ov, 1e4 * t_base)
             except Exception as e:  # noqa: BLE001
                 print("halo transport tuning failed: %r" % (e,), file=sys.stderr)
                 slab.set_halo_p2p(False)
+                slab.set_overlap(False)
             wall_l, fin_l = measure()
             driver += "; torch.distributed driver: %.1f us/step" % (1e6 * wall_t / args.steps)
             try:  # what the exchanges cost by themselves on this node (for the record)
@@ -422,6 +435,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
     slab.close()
     lib_ok = lib_status == "ok" and best[2].startswith("library")
     p2p = "halo rows by send/recv" in best[2]
+    ovl = bool(lib_ok and extra.get("halo_overlap", {}).get("used", False))
     if os.environ.get("QGCM_BENCH_NO_SECONDARY") != "1":
         import threading
         from qgcm_hip import preset
@@ -438,7 +452,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         # (1) strong scaling: the FIXED NAtl 5 km basin (961 x 961 x 3, BASELINE configs[1]) cut into `world` slabs
         try:
             extra["strong_scaling_natl5"] = slab_secondary(cfg5, world, rank, local_rank, barrier, lib_ok, p2p, 400, 100,
-                                                           "double_gyre_ocean_only NAtl 5km, fixed basin over %d GPUs" % world)
+                                                           "double_gyre_ocean_only NAtl 5km, fixed basin over %d GPUs" % world, overlap=ovl)
         except Exception as e:  # noqa: BLE001 - secondary figure only
             extra["strong_scaling_natl5"] = {"error": repr(e)}
         # (2) BASELINE configs[4]: NAtl 1 km (4801 x 4801 x 3, dto = 180 s) over the GPUs of the node; one slab may hold
@@ -446,7 +460,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         if world >= 3:
             try:
                 extra["natl1km"] = slab_secondary(preset("natl1"), world, rank, local_rank, barrier, lib_ok, p2p, 100, 20,
-                                                  "NAtl 1km ocean-only, 3 layers, y-slabs over %d GPUs" % world)
+                                                  "NAtl 1km ocean-only, 3 layers, y-slabs over %d GPUs" % world, overlap=ovl)
             except Exception as e:  # noqa: BLE001
                 extra["natl1km"] = {"error": repr(e)}
         # (2b) the fixed NAtl 5 km basin with the ocean mixed layer on the slabs (three exchanges per step)
@@ -458,7 +472,7 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
         # (3) BASELINE configs[2]: Southern Ocean 5 km periodic channel (4609 x 577 x 3) cut into `world` slabs
         try:
             extra["socn5_cyclic_slabs"] = slab_secondary(preset("socn5"), world, rank, local_rank, barrier, lib_ok, p2p, 200, 40,
-                                                         "SOcn 5km cyclic channel, fixed basin over %d GPUs" % world)
+                                                         "SOcn 5km cyclic channel, fixed basin over %d GPUs" % world, overlap=ovl)
         except Exception as e:  # noqa: BLE001
             extra["socn5_cyclic_slabs"] = {"error": repr(e)}
         dog2.cancel()

@@ -224,6 +224,10 @@ int qgcm_hip_area_integrals(qgcm_hip_handle h, double *xin);
  *   stage 2: thomas_phase(2), constr, row_transform(1), unpack(+ocqbdy), halo_pack
  *                                                      a = summary gather buffer, b/c = halo to-lower/to-upper
  *   stage 3: halo_unpack, optional lf_average (flags & 1)                        a/b = halo from-lower/from-upper
+ *   stage 4 + stage 5 = stage 1 in two parts, for drivers that overlap the halo exchange with compute: stage 4 is the
+ *            part of the tendency launch that reads no halo row (all but the first and last 16-row tile row; it may
+ *            run before stage 3 of the previous step), stage 5 the rest of stage 1 (a = summary send buffer).  Needs
+ *            at least three tile rows per slab and the mixed layer off.
  * With the ocean mixed layer on the device (qgcm_hip_oml_init on every slab, before the buffers are sized) `call oml`
  * (src/q-gcm.F:1232) runs before stage 1, in two halves around ONE more all-gather of qgcm_hip_oml_msg_len() doubles
  * per rank (the mean entrainment is a basin-wide number, src/omlsubs.F:153):
@@ -254,6 +258,11 @@ int qgcm_hip_slab_steps(qgcm_hip_handle h, int s0, int n);
 /* edge rows as grouped send/recv with the two neighbours (1) or as one all-gather (0); collective:
  * every rank must make the same choice */
 int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle h, int on);
+/* on = 1: the halo exchange of step s (and the halo unpack) run on a second stream while the handle's stream already
+ * computes the tile rows of step s+1's tendency launch that need no halo row (stage 4), then waits and finishes
+ * (stage 5).  Bitwise the same results.  Steps followed by a leapfrog averaging, the mixed layer and slabs of fewer
+ * than three 16-row tile rows keep the plain order.  Collective choice, like the one above. */
+int qgcm_hip_comm_set_overlap(qgcm_hip_handle h, int on);
 /* measurement aid (collective): the step's exchanges back to back, microseconds each:
  * us[0] summaries all-gather, us[1] halo rows as all-gather, us[2] halo rows as send/recv */
 int qgcm_hip_comm_probe(qgcm_hip_handle h, int reps, double *us);

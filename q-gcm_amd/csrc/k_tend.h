@@ -192,8 +192,8 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   // row are walls whose update is point-wise (no stencil), so they are peeled off into a few "edge"
   // workgroups instead of a whole extra column / row of nearly empty tiles (tend_edge below).
   const TendTiling T = tend_tiling<CYC>(P.g);
-  const int gx = T.gx, gy = T.gy;
-  const int ntiles = gx * gy;
+  const int gx = T.gx;
+  const int ntiles = gx * (P.trows ? P.trows : T.gy); // (a window of the tile rows, or all of them)
   const int per_xcd = (ntiles + 7) / 8;
   if (F.on && blockIdx.x == 0) {
     // mixed layer on, inside qgcm_hip_steps: the last reduction of `oml` (xon(1), enisoc(1) / eninoc(1), monitors) is
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
   const int i0 = (tile % gx) * TX + 1; // first global i of the tile (1-based)
-  const int j0 = (tile / gx) * TY + jlo; // first local row of the tile
+  const int trow = P.trows ? P.trow0 + (tile / gx) * P.tstride : tile / gx;
+  const int j0 = trow * TY + jlo; // first local row of the tile
   const int tx = tid % TX;
   const int ty0 = tid / TX; // 0..3
   constexpr int RPT = TY / (TEND_NT / TX); // rows per thread

@@ -69,6 +69,10 @@ struct QgTendParams {
   // workgroup of the fused inverse-transform kernel (k_dst64_unpack<.., CONSTR>) without a launch of its own
   int upd_dpi;
   double gpoc[QG_MAXL];
+  // window of tile rows (y-slabs, halo exchange overlapped with the tendency of the next step): trows == 0 -> all tile
+  // rows; else this launch does the tile rows trow0 + r*tstride, r = 0..trows-1, and carries no edge / line-sum
+  // workgroups unless the host appended them to the grid (they belong to the launch that follows the halo rows)
+  int trow0, trows, tstride;
 };
 
 struct QgDstParams {

@@ -275,6 +275,9 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   if (c->sc_comm) {
     QgSlabComm *m = c->sc_comm;
     if (m->comm) m->api->CommDestroy(m->comm);
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_halo) hipEventDestroy(m->ev_halo);
+    if (m->cstream) hipStreamDestroy(m->cstream);
     double *cb[] = {m->th_send, m->th_gath, m->h_send, m->h_gath, m->oml_send, m->oml_gath};
     for (double *p : cb)
       if (p) hipFree(p);
@@ -740,7 +743,17 @@ static void drain_timers(qgcm_hip_ctx *c) {
 
 static void fill_oml_final(qgcm_hip_ctx *c, QgOmlFinal &F, bool on);
 
-static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = false) {
+// part: TEND_ALL = the whole launch; TEND_INNER = the tile rows whose stencils stay inside the owned rows (they need no
+// halo row: y-slabs run them while the halo exchange of the previous step is still under way) plus the one-thread /
+// one-workgroup riders of workgroup 0; TEND_OUTER = the first and the last tile row plus the edge / line-sum workgroups.
+// INNER followed by OUTER writes what ALL writes, bit for bit (tiles are independent).
+enum { TEND_ALL = 0, TEND_INNER = 1, TEND_OUTER = 2 };
+static bool tend_can_split(const qgcm_hip_ctx *c) {
+  const TendTiling T = c->g.cyc ? tend_tiling<true>(c->g) : tend_tiling<false>(c->g);
+  return T.gy >= 3;
+}
+
+static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = false, int part = TEND_ALL) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
   QgTendParams P;
@@ -768,7 +781,10 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   P.upd_dpi = upd_dpi ? 1 : 0;
   for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
   const TendTiling T = g.cyc ? tend_tiling<true>(g) : tend_tiling<false>(g);
-  const int ntiles = T.gx * T.gy;
+  if (part != TEND_ALL && T.gy < 3) QG_FAIL("k_tend: a slab of fewer than three tile rows cannot be split");
+  if (part == TEND_INNER) { P.trow0 = 1; P.trows = T.gy - 2; P.tstride = 1; }
+  if (part == TEND_OUTER) { P.trow0 = 0; P.trows = 2; P.tstride = T.gy - 1; P.upd_dpi = 0; }
+  const int ntiles = T.gx * (part == TEND_ALL ? T.gy : P.trows);
   // cyclic: the boundary line sums for the momentum constraints (state before the step) ride as extra workgroups
   QgCycSumParams S;
   memset(&S, 0, sizeof(S));
@@ -780,8 +796,8 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
     S.dxo = pr.dxo; S.dyo = pr.dyo;
   }
   QgOmlFinal F;
-  fill_oml_final(c, F, oml_final && c->oml.on);
-  const int nextra = g.cyc ? g.nl * 2 * BSUM_NB : T.nedge;
+  fill_oml_final(c, F, oml_final && c->oml.on && part != TEND_OUTER);
+  const int nextra = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : T.nedge);
   dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
 #define QG_TEND(NLV)                                                                              \
@@ -2062,19 +2078,24 @@ static int oml_halo_pack(qgcm_hip_ctx *c, double *to_lo, double *to_hi) {
 extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, double *b, double *cc, int rank, int nranks,
                                    int flags) {
   switch (stage) {
-    case 1: {
-      if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 1 needs the send buffer");
+    case 1:
+    case 4:   // the part of stage 1 that needs no halo row: the inner tile rows of the tendency launch
+    case 5: { // the rest of stage 1: outer tile rows + edge work, forward rows, summary sweep
+      if (stage != 4 && !a) QG_FAIL("qgcm_hip_slab_stage: stage %d needs the send buffer", stage);
       if (check_ready(c, "qgcm_hip_slab_stage")) return 1;
+      if (stage != 1 && (c->oml.on || !tend_can_split(c)))
+        QG_FAIL("qgcm_hip_slab_stage: stages 4 / 5 need a slab of at least three tile rows (%d rows each) and the mixed layer off", TEND_TY);
       // cyclic: the boundary line sums of the tendency launch go straight into the tail of the step message
-      if (c->g.cyc) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
+      if (c->g.cyc && stage != 4) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
       // box fast path: as in qgcm_hip_steps the leapfrog of dpioc is done by the tendency launch and the constraint
       // solve by the extra wave of the fused inverse-transform kernel of stage 2 (no k_constr_box launch)
       if (!c->homog_set) QG_FAIL("qgcm_hip_slab_stage: homogeneous solutions not set");
       // (with the mixed layer on, xon(1) is only complete after the all-gather: dpioc is stepped in stage 2 then)
       const bool fused_constr = can_fuse_dst_unpack(c) && !c->no_fused_constr && !c->oml.on; // can_fuse: box ocean only
-      const int rc = launch_tend(c, fused_constr);
+      const int rc = launch_tend(c, fused_constr, false, stage == 1 ? TEND_ALL : stage == 4 ? TEND_INNER : TEND_OUTER);
       c->bpart_out = nullptr;
       if (rc) return 1;
+      if (stage == 4) return 0;
       c->iq ^= 1; // as qgcm_hip_qgostep
       if (qgcm_hip_row_transform(c, 0)) return 1;
       if (qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks)) return 1;
@@ -2136,7 +2157,7 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
       if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 11 needs the gathered sums");
       c->oml_gath = a;
       return launch_oml_b(c, a, nranks);
-    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..3, 10 or 11");
+    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..5, 10 or 11");
   }
 }
 
@@ -2213,6 +2234,26 @@ extern "C" int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle c, int on) {
   return 0;
 }
 
+// Halo exchange of step s overlapped with the inner tile rows of step s+1's tendency launch: the exchange and the halo
+// unpack go to a second stream; the handle's stream runs k_tend's inner tile rows (stage 4), waits for the halo rows,
+// and goes on with the outer tile rows (stage 5).  Same results, bit for bit.  Not with the mixed layer on (its first
+// stage needs the neighbours' sst rows), not across a leapfrog averaging, not for slabs of fewer than three tile rows:
+// those steps keep the plain order.
+extern "C" int qgcm_hip_comm_set_overlap(qgcm_hip_handle c, int on) {
+  if (!c || !c->sc_comm) QG_FAIL("qgcm_hip_comm_set_overlap: no communicator (qgcm_hip_comm_init)");
+  QgSlabComm *m = c->sc_comm;
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  if (m->overlap != (on != 0)) drop_graphs(c); // captured steps contain the old order
+  if (on && !m->cstream) {
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamCreateWithFlags(&m->cstream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&m->ev_halo, hipEventDisableTiming));
+  }
+  m->overlap = (on != 0);
+  return 0;
+}
+
 // Measurement aid: the step's collectives issued back to back on the handle's stream, HIP-event timed
 // (collective over all ranks). us[0] = all-gather of the slab summaries, us[1] = halo rows as one all-gather,
 // us[2] = halo rows as grouped send/recv with the two neighbours.
@@ -2275,37 +2316,70 @@ static int slab_step(qgcm_hip_ctx *c, int s) {
     if (qgcm_hip_slab_stage(c, 11, m->oml_gath, nullptr, nullptr, r, P, 0)) return 1;
   }
   // 1. tendency, forward row transform, slab summary of the two y sweeps
-  if (qgcm_hip_slab_stage(c, 1, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
+  if (m->pending) {
+    // the halo rows of the previous step are still on their way (second stream): inner tile rows first
+    if (qgcm_hip_slab_stage(c, 4, nullptr, nullptr, nullptr, r, P, 0)) return 1;
+    HIPCHECK(hipStreamWaitEvent(c->stream, m->ev_halo, 0));
+    m->pending = false;
+    if (qgcm_hip_slab_stage(c, 5, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
+  } else if (qgcm_hip_slab_stage(c, 1, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
   NCCLCHECK(m->api, m->api->AllGather(m->th_send, m->th_gath, m->th_len, ncclDouble, m->comm, c->stream));
   // 2. both sweeps from the composed inflows (+ basin-wide area integrals), constraints, inverse row transform,
   //    modes -> layers + boundary PV, edge rows out
   double *to_lo = r > 0 ? m->h_send : nullptr, *to_hi = r < P - 1 ? m->h_send + n : nullptr;
   if (qgcm_hip_slab_stage(c, 2, m->th_gath, to_lo, to_hi, r, P, 0)) return 1;
+  const int avg = (s - 1) % 25 == 0 ? 1 : 0; // leapfrog averaging after steps s with (s-1) mod 25 == 0
+  // overlapped: the exchange and the halo unpack on the second stream; the next step's stage 4 does not wait for them
+  const bool ov = m->overlap && !avg && !c->oml.on && tend_can_split(c);
+  hipStream_t xs = c->stream;
+  if (ov) {
+    HIPCHECK(hipEventRecord(m->ev_fork, c->stream));
+    HIPCHECK(hipStreamWaitEvent(m->cstream, m->ev_fork, 0));
+    xs = m->cstream;
+  }
   const double *from_lo = nullptr, *from_hi = nullptr;
-  if (P > 1) {
-    if (m->halo_p2p) {
+  if (P > 1 || ov) { // (one rank, overlapped: the all-gather is a local copy - it keeps the one-GPU tests on this path)
+    if (m->halo_p2p && P > 1) {
       // neighbours only; receive areas are the neighbour's slots of h_gath, as with the all-gather
       double *rl = m->h_gath + (size_t)(2 * (r > 0 ? r - 1 : 0) + 1) * n, *rh = m->h_gath + (size_t)(2 * (r < P - 1 ? r + 1 : 0)) * n;
       NCCLCHECK(m->api, m->api->GroupStart());
       if (r > 0) {
-        NCCLCHECK(m->api, m->api->Send(to_lo, n, ncclDouble, r - 1, m->comm, c->stream));
-        NCCLCHECK(m->api, m->api->Recv(rl, n, ncclDouble, r - 1, m->comm, c->stream));
+        NCCLCHECK(m->api, m->api->Send(to_lo, n, ncclDouble, r - 1, m->comm, xs));
+        NCCLCHECK(m->api, m->api->Recv(rl, n, ncclDouble, r - 1, m->comm, xs));
       }
       if (r < P - 1) {
-        NCCLCHECK(m->api, m->api->Send(to_hi, n, ncclDouble, r + 1, m->comm, c->stream));
-        NCCLCHECK(m->api, m->api->Recv(rh, n, ncclDouble, r + 1, m->comm, c->stream));
+        NCCLCHECK(m->api, m->api->Send(to_hi, n, ncclDouble, r + 1, m->comm, xs));
+        NCCLCHECK(m->api, m->api->Recv(rh, n, ncclDouble, r + 1, m->comm, xs));
       }
       NCCLCHECK(m->api, m->api->GroupEnd());
     } else {
-      NCCLCHECK(m->api, m->api->AllGather(m->h_send, m->h_gath, 2 * n, ncclDouble, m->comm, c->stream));
+      NCCLCHECK(m->api, m->api->AllGather(m->h_send, m->h_gath, 2 * n, ncclDouble, m->comm, xs));
     }
     if (r > 0) from_lo = m->h_gath + (size_t)(2 * (r - 1) + 1) * n;  // what the lower neighbour sent upwards
     if (r < P - 1) from_hi = m->h_gath + (size_t)(2 * (r + 1)) * n;  // what the upper neighbour sent downwards
   }
-  // 3. edge rows in, leapfrog averaging after steps s with (s-1) mod 25 == 0
-  const int avg = (s - 1) % 25 == 0 ? 1 : 0;
-  if (P > 1 || avg)
-    if (qgcm_hip_slab_stage(c, 3, (double *)from_lo, (double *)from_hi, nullptr, r, P, avg)) return 1;
+  // 3. edge rows in (+ leapfrog averaging)
+  if (P > 1 || avg) {
+    hipStream_t main_stream = c->stream;
+    c->stream = xs; // (the stage's launches follow the exchange on its stream)
+    const int rc = qgcm_hip_slab_stage(c, 3, (double *)from_lo, (double *)from_hi, nullptr, r, P, avg);
+    c->stream = main_stream;
+    if (rc) return 1;
+  }
+  if (ov) {
+    HIPCHECK(hipEventRecord(m->ev_halo, m->cstream));
+    m->pending = true;
+  }
+  return 0;
+}
+
+// the second stream joins the handle's stream (end of a qgcm_hip_slab_steps call, end of a captured block)
+static int slab_join(qgcm_hip_ctx *c) {
+  QgSlabComm *m = c->sc_comm;
+  if (m && m->pending) {
+    HIPCHECK(hipStreamWaitEvent(c->stream, m->ev_halo, 0));
+    m->pending = false;
+  }
   return 0;
 }
 
@@ -2323,7 +2397,9 @@ static int get_slab_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
   for (int k = 0; k < kGraphBlock && !rc; ++k) rc = slab_step(c, s0 + k);
+  if (!rc) rc = slab_join(c);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc && c->sc_comm) c->sc_comm->pending = false;
   c->ip = ip0; // nothing ran: the rotation state is that of the block's first step
   c->iq = iq0;
   c->oml.is = is0;
@@ -2354,7 +2430,7 @@ extern "C" int qgcm_hip_slab_steps(qgcm_hip_handle c, int s0, int n) {
   }
   for (; n > 0; --n, ++s)
     if (slab_step(c, s)) return 1;
-  return 0;
+  return slab_join(c);
 }
 
 extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) {

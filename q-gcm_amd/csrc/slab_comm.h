@@ -63,4 +63,9 @@ struct QgSlabComm {
   double *th_send = nullptr, *th_gath = nullptr; // slab summaries of the y sweeps (k_thomas.h, TH_MSG per mode and wavenumber)
   double *h_send = nullptr, *h_gath = nullptr;   // edge rows: [to lower | to upper] per rank
   double *oml_send = nullptr, *oml_gath = nullptr; // mixed layer: the three sums of a slab's k_oml_step (3 per rank)
+  // halo exchange overlapped with the inner tile rows of the next step's tendency launch (qgcm_hip_comm_set_overlap):
+  // the exchange and the halo unpack run on cstream, forked from / joined to the handle's stream by events
+  bool overlap = false, pending = false;
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_halo = nullptr;
 };

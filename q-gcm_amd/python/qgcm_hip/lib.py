@@ -54,7 +54,7 @@ SYMBOLS = [
     "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
     "qgcm_hip_constr", "qgcm_hip_unpack",
     "qgcm_hip_halo_msg_len", "qgcm_hip_halo_pack", "qgcm_hip_halo_unpack", "qgcm_hip_slab_stage", "qgcm_hip_oml_msg_len",
-    "qgcm_hip_comm_unique_id", "qgcm_hip_comm_init", "qgcm_hip_slab_steps", "qgcm_hip_comm_set_halo_p2p", "qgcm_hip_comm_probe",
+    "qgcm_hip_comm_unique_id", "qgcm_hip_comm_init", "qgcm_hip_slab_steps", "qgcm_hip_comm_set_halo_p2p", "qgcm_hip_comm_set_overlap", "qgcm_hip_comm_probe",
     "qgcm_hip_oml_init", "qgcm_hip_oml_set_state", "qgcm_hip_oml_get_state", "qgcm_hip_oml_set_forcing",
     "qgcm_hip_oml", "qgcm_hip_oml_get_diag", "qgcm_hip_set_dtopoc", "qgcm_hip_valids",
     "qgcm_hip_init_from_p", "qgcm_hip_wekpo_from_tau", "qgcm_hip_prsamp",
@@ -121,6 +121,7 @@ def load_library():
     L.qgcm_hip_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_int]
     L.qgcm_hip_slab_steps.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_comm_set_halo_p2p.argtypes = [vp, C.c_int]
+    L.qgcm_hip_comm_set_overlap.argtypes = [vp, C.c_int]
     L.qgcm_hip_comm_probe.argtypes = [vp, C.c_int, dp]
     L.qgcm_hip_oml_init.argtypes = [vp, C.POINTER(OmlParams)]
     L.qgcm_hip_oml_set_state.argtypes = [vp, dp, dp]

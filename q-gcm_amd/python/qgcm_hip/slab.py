@@ -403,6 +403,10 @@ class HipSlab:
     def set_halo_p2p(self, on):
         check(self.L.qgcm_hip_comm_set_halo_p2p(self.h, int(on)))
 
+    def set_overlap(self, on):
+        """Library-issued exchanges: halo exchange on a second stream under the next step's inner tendency tiles."""
+        check(self.L.qgcm_hip_comm_set_overlap(self.h, int(on)))
+
     def slab_steps(self, s0, n):
         check(self.L.qgcm_hip_slab_steps(self.h, int(s0), int(n)))
         self._done()
@@ -416,6 +420,14 @@ class HipSlab:
 # --------------------------------------------------------------------------
 # orchestration
 # --------------------------------------------------------------------------
+def tend_tile_rows(cfg, g0, g1):
+    """Tile rows of the tendency launch on the slab of global rows g0..g1 (k_tend.h tend_tiling: 16-row tiles; the
+    northern wall row of a box basin is peeled off when it would open a tile row of its own)."""
+    rows = g1 - g0 + 1
+    peel = (not cfg.cyclic) and rows % 16 == 1 and rows > 1 and g1 == cfg.nypo
+    return rows // 16 if peel else -(-rows // 16)
+
+
 class SlabOcean:
     """The distributed ocean step.  `slabs` are the slab objects this process owns
     (one per local rank of `comm`); a slab object provides the methods of HipSlab."""
@@ -478,8 +490,19 @@ class SlabOcean:
             self._comm(cm.all_gather, self.om_gath, self.om_send)
             for i, x in enumerate(S):
                 x.stage(11, self.om_gath[i])
-        for i, x in enumerate(S):  # tendency, forward row transform, slab summary of the y sweeps
-            x.stage(1, self.th_send[i])
+        if getattr(self, "_halo_pending", False):
+            # early_tend: the halo rows of the previous step have not been unpacked yet - the inner tile rows of the
+            # tendency launch do not read them (stage 4); then halo rows in (stage 3) and the rest of stage 1 (stage 5)
+            for x in S:
+                x.stage(4)
+            for i, x in enumerate(S):
+                x.stage(3, self.h_from_lo[i], self.h_from_hi[i], None, 0)
+            self._halo_pending = False
+            for i, x in enumerate(S):
+                x.stage(5, self.th_send[i])
+        else:
+            for i, x in enumerate(S):  # tendency, forward row transform, slab summary of the y sweeps
+                x.stage(1, self.th_send[i])
         self._comm(cm.all_gather, self.th_gath, self.th_send)
         # both sweeps + basin-wide area integrals, constraints, inverse row transform,
         # modes -> layers (+ boundary PV), halo rows out
@@ -488,9 +511,19 @@ class SlabOcean:
         if self.P > 1:
             self._comm(cm.halo_exchange, self.h_to_lo, self.h_to_hi, self.h_from_lo, self.h_from_hi)
         avg = 1 if (s - 1) % 25 == 0 else 0
+        if (getattr(self, "early_tend", False) and self.P > 1 and not avg and not self.oml_on
+                and all(tend_tile_rows(self.cfg, x.g0, x.g1) >= 3 for x in S)):
+            self._halo_pending = True  # stage 3 of this step follows stage 4 of the next one (the order the library's
+            return                     # overlapped exchange produces, qgcm_hip_comm_set_overlap)
         if self.P > 1 or avg:
             for i, x in enumerate(S):  # halo rows in, leapfrog averaging every 25th step
                 x.stage(3, self.h_from_lo[i], self.h_from_hi[i], None, avg)
+
+    def _join(self):
+        if getattr(self, "_halo_pending", False):
+            for i, x in enumerate(self.slabs):
+                x.stage(3, self.h_from_lo[i], self.h_from_hi[i], None, 0)
+            self._halo_pending = False
 
     def homsol(self):
         """homsol of the box ocean (src/conhoms.F:549-641) ON the slabs: the modal Helmholtz problems of a step are
@@ -542,6 +575,7 @@ class SlabOcean:
         else:
             for s in range(s0, s0 + int(n)):
                 self.step(s)
+            self._join()
         self.step_index = s0 + int(n)
 
     # helpers to scatter / gather global arrays (host side, for tests and set-up) --

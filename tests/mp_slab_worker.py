@@ -2,7 +2,8 @@
 duplicate devices), each compared bitwise with the same decomposition run as virtual ranks inside this process.
 What this covers and the virtual-rank tests cannot: asynchronous stage calls (no synchronisation after every call),
 set-up exchanges between separate handles in separate processes, the DistComm transports.
-usage (under torch.distributed.run): mp_slab_worker.py <preset> <halo: allgather|p2p> [oml]"""
+usage (under torch.distributed.run): mp_slab_worker.py <preset> <halo: allgather|p2p> [oml|early]
+(early: stage 4 of the next step before stage 3 - the order of the overlapped halo exchange - in this process's run)"""
 import os
 import sys
 
@@ -34,7 +35,7 @@ def main():
     parts = partition(cfg.nypo, P)
     # the reference: all P slabs as virtual ranks in this process
     vs = [HipSlab(cfg, consts, g0, g1, r, P, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
-    with_oml = len(sys.argv) > 3 and sys.argv[3] == "oml"  # mixed layer on: one more small all-gather per step
+    with_oml = "oml" in sys.argv[3:]  # mixed layer on: one more small all-gather per step
     if with_oml:
         om = oml_preset(cfg, sb_hflux=True, nb_hflux=False)
         sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om, seed=7)
@@ -59,6 +60,7 @@ def main():
         slab.oml_init(om)
     torch.cuda.set_stream(torch.cuda.ExternalStream(slab.stream_ptr, device=slab.device))
     so = SlabOcean(cfg, [slab], DistComm(halo_via_all_gather=(sys.argv[2] != "p2p")))
+    so.early_tend = "early" in sys.argv[3:]
     ok = True
     if not cyc:
         dh = so.homsol()

@@ -97,10 +97,18 @@ def test_slab_handles_refuse_whole_domain_entry_points():
             check(sl.L.qgcm_hip_steps(sl.h, 1, 1))
         with pytest.raises(QgcmHipError, match="whole domain"):
             check(sl.L.qgcm_hip_valids(sl.h, None, None))
-        with pytest.raises(QgcmHipError, match="stage must be 1..3"):
-            sl.stage(4)
+        with pytest.raises(QgcmHipError, match="stage must be 1..5"):
+            sl.stage(6)
     finally:
         sl.close()
+    # the split tendency launch (stages 4 / 5) needs three 16-row tile rows: a 20-row slab refuses
+    (g0, g1) = partition(cfg.nypo, 4)[1]
+    thin = HipSlab(cfg, consts, g0, g1, 1, 4)
+    try:
+        with pytest.raises(QgcmHipError, match="at least three tile rows"):
+            thin.stage(4)
+    finally:
+        thin.close()
 
 
 def test_mixed_layer_on_slabs_misuse():

@@ -15,10 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("name,halo,extra", [("box_small", "allgather", ""), ("box_small", "p2p", ""), ("box_med", "allgather", ""),
                                              ("cyc_med", "allgather", ""), ("cyc_small", "p2p", ""),
-                                             ("box_small", "p2p", "oml"), ("cyc_small", "allgather", "oml")])
+                                             ("box_small", "p2p", "oml"), ("cyc_small", "allgather", "oml"),
+                                             ("box_med", "p2p", "early"), ("box_med", "allgather", "early")])
 def test_three_processes_one_slab_each(name, halo, extra):
     port = 29600 + (hash((name, halo, extra)) % 300)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+    nproc = "2" if extra == "early" else "3"  # (early: slabs of at least three 16-row tile rows - 97 rows make two)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", nproc, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "mp_slab_worker.py"), name, halo] + ([extra] if extra else [])
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)

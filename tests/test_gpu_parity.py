@@ -766,7 +766,10 @@ def test_library_issued_exchanges_one_rank(name, graph, with_oml, monkeypatch):
     itself, on a real (one-rank) RCCL communicator -- all a one-GPU box can hold; eager and as
     50-step HIP graphs that contain the collectives.  Bitwise equal to the same slab kernels
     driven stage by stage from Python (the path the virtual-rank tests pin to the oracle).  Box and cyclic ocean,
-    and with the ocean mixed layer on (its own small all-gather inside the step, three graphs for the sst rotation)."""
+    and with the ocean mixed layer on (its own small all-gather inside the step, three graphs for the sst rotation).
+    Third run: qgcm_hip_comm_set_overlap - the halo exchange (here a one-rank all-gather) and stage 3 on a second stream,
+    forked and joined by events (inside the captured graphs too), the tendency launch split into its inner and outer
+    tile rows; with the mixed layer on the switch must change nothing."""
     import torch
     from qgcm_hip import hostinit, oml_preset, synth
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, rccl_unique_id
@@ -789,7 +792,7 @@ def test_library_issued_exchanges_one_rank(name, graph, with_oml, monkeypatch):
             om = oml_preset(cfg, sb_hflux=True, nb_hflux=True)
             sst, sstm, fnet, tx, ty = synth.mixed_layer_fields(cfg, om, seed=3)
             wekto, wek = synth.wekpo_from_tau(cfg, tx, ty)
-        for native in (False, True):
+        for native in (False, True, "overlap"):
             sl = HipSlab(cfg, consts, 1, cfg.nypo, 0, 1, sync_each_call=not native)
             slabs.append(sl)
             if with_oml:
@@ -803,16 +806,67 @@ def test_library_issued_exchanges_one_rank(name, graph, with_oml, monkeypatch):
                 sl.oml_set_forcing(fnet, wekto, tx, ty)
             if native:
                 so.use_library_exchanges(rccl_unique_id())
+            if native == "overlap":
+                sl.set_overlap(1)
             so.steps(107 if with_oml else 57, s0=1)   # graph mode: 50-step block(s) + 7 eager steps
             sl.sync()
             out.append((sl.get_state() + (sl.oml_get_state() if with_oml else []), sl.get_scalars()))
-        for x, y in zip(out[0][0], out[1][0]):
-            assert np.array_equal(x, y)
-        assert np.array_equal(out[0][1], out[1][1])
+        for other in out[1:]:
+            for x, y in zip(out[0][0], other[0]):
+                assert np.array_equal(x, y)
+            assert np.array_equal(out[0][1], other[1])
     finally:
         for sl in slabs:
             sl.close()
         o.close()
+
+
+@pytest.mark.parametrize("cyclic,nslab", [(False, 2), (False, 3), (True, 2)])
+def test_inner_tendency_tiles_need_no_halo_rows(cyclic, nslab):
+    """The order the overlapped halo exchange produces (qgcm_hip_comm_set_overlap), run sequentially on virtual ranks:
+    stage 4 of step s+1 (inner tile rows of the tendency launch) BEFORE stage 3 of step s (halo rows in), then stage 5.
+    If an inner tile read a halo row it would read the rows of the step before: the run must stay bitwise equal to
+    the plain order.  60 steps from a noisy state, across the averaging steps (which keep the plain order)."""
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.config import OceanConfig
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    base = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True) if cyclic else dict(fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
+    cfg = OceanConfig("early_%s" % ("cyc" if cyclic else "box"), 12 if cyclic else 16, 12, 12, 7, 16, 3, dxo=2.5e4, dta=240.0,
+                      ah4oc=(1.2e10,) * 3, **base)
+    assert cfg.nypo >= 33 * nslab  # at least three 16-row tile rows per slab
+    consts = global_consts(cfg)
+    po = synth.gaussian_eddy(cfg, noise=2e-2, seed=21)
+    pom = np.asfortranarray(0.99 * po)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    ent = np.zeros_like(wek)
+    xon = np.zeros(cfg.nlo - 1)
+    qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+    qom = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], pom)
+    scal = hostinit.constr(cfg, consts["amatoc"], po, pom)
+    txis, txin = synth.tau_line_integrals(cfg, tx) if cyclic else (0.0, 0.0)
+    outs = []
+    for early in (False, True):
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nslab, sync_each_call=True) for r, (g0, g1) in enumerate(partition(cfg.nypo, nslab))]
+        try:
+            so = SlabOcean(cfg, slabs, LocalComm(nslab, after=torch.cuda.synchronize))
+            so.early_tend = early
+            if not cyclic:
+                so.homsol()
+            so.scatter_state(po, pom, qo, qom, wek, ent, xon, scal)
+            for x in slabs:
+                if cyclic:
+                    x.set_cyc_forcing(txis, txin)
+            so.steps(60, s0=1)
+            outs.append(([f.copy() for _, _, fs in so.gather_local() for f in fs], slabs[0].get_scalars()))
+        finally:
+            for x in slabs:
+                x.close()
+    assert all(np.isfinite(f).all() for f in outs[0][0])
+    for x, y in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(outs[0][1], outs[1][1])
 
 
 def test_bench_n8_workload_as_virtual_ranks():
