@@ -260,6 +260,11 @@ module qgcm_hip_iface
       type(c_ptr), value :: h
       integer(c_int), value :: on
     end function
+    integer(c_int) function qgcm_hip_comm_set_overlap(h, on) bind(C, name='qgcm_hip_comm_set_overlap')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+    end function
   end interface
 
 contains
