@@ -348,7 +348,9 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   __shared__ __align__(16) cplx Fsh[D64_WAVES][M * D64_ROW];
   __shared__ __align__(16) cplx W64sh[D64_WAVES][64]; // exp(-2 pi i t / 64), per wave copy
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  // (the wave's number as a scalar: the row pointers below are then uniform - one SGPR pair plus 32-bit lane offsets
+  //  per load / store instead of a 64-bit address computed in VGPRs for each)
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ny = P.g.ny, ldw = P.g.ldw;
   const int m = blockIdx.y + P.layer0;
   const int pair = blockIdx.x * D64_WAVES + wv;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
   __shared__ double hc_sh[NL];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = tid >> 6; // = mode (NL: the constraint wave)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // = mode (NL: the constraint wave); scalar: uniform row pointers
   const int ldw = P.g.ldw;
   const int ja = P.g.jr0 + 2 * blockIdx.x;     // local rows ja, ja+1 (grid is exactly the pairs)
   const bool has_b = (ja + 1 <= P.g.jr1);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(D64_NT) void k_rfft64(const QgDstParams P) {
   __shared__ __align__(16) cplx Fsh[D64_WAVES][M * D64_ROW];
   __shared__ __align__(16) cplx W64sh[D64_WAVES][64];
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // scalar: uniform row pointers (k_dst64.h)
   const int m = blockIdx.y + P.layer0;
   const int pair = blockIdx.x * D64_WAVES + wv;
   const int ja = P.g.jr0 + 2 * pair;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_rfft64_unpack(
   __shared__ double cc_sh[2 * NL + 1]; // c1(1..NL-1), c2(1..NL-1), c3
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = tid >> 6; // = mode
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // = mode (scalar: uniform row pointers)
   const int ny = U.g.ny, nx = U.g.nx, nxt = U.g.nxt;
   if (CONSTR && wv == NL) { // the constraint wave
     double c1[NL], c2[NL], c3, ocs[NL], ocn[NL];
