@@ -333,6 +333,10 @@ int qgcm_hip_prsamp(qgcm_hip_handle h, double *out);
 /* Runs n steps like qgcm_hip_steps and returns the HIP-event time (ms) of
  * the whole region, measured on the handle's stream. */
 int qgcm_hip_time_steps(qgcm_hip_handle h, int s0, int n, float *ms);
+/* Captures, instantiates and uploads the HIP graphs qgcm_hip_steps(s0, n) will replay (50-step blocks + one block
+ * for the even part of the remainder) without running a step, so that a caller timing a window with its own clock
+ * keeps graph construction outside it.  Synchronous; the state is untouched. */
+int qgcm_hip_prepare_steps(qgcm_hip_handle h, int s0, int n);
 /* Runs n steps eagerly with HIP events around every kernel launch and
  * accumulates per-kernel totals: ms[i], launches[i] for i < *nk (in: capacity,
  * out: number of kernel slots).  names[i] points to static strings. */

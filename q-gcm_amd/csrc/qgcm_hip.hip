@@ -132,9 +132,12 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Captured step graphs hold kernel parameters by value and raw device pointers: every call that changes
 // either (tables, homogeneous solutions, mixed-layer parameters, slab constants) drops them.
+// The stream is drained even when no graph exists: the callers go on to overwrite device tables with blocking copies
+// on the null stream, which the handle's non-blocking stream does not wait for - eager steps still in flight would
+// read half-updated tables (all callers are set-up calls: the wait costs nothing that matters).
 static void drop_graphs(qgcm_hip_ctx *c) {
-  if (c->graphs.empty() && c->slab_graphs.empty()) return;
   (void)hipStreamSynchronize(c->stream);
+  if (c->graphs.empty() && c->slab_graphs.empty()) return;
   for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
   for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second);
   c->graphs.clear();
@@ -1760,9 +1763,13 @@ static void oml_rotate(qgcm_hip_ctx *c, int nsteps) {
 
 // One captured block of B consecutive steps. B is even, so both buffer rotations are back where they started
 // after the block; the key carries everything else a captured step depends on: the position in the averaging
-// cycle and the sst rotation. 50-step blocks serve long runs (one graph for the ocean: 50 = 2 x 25), 10-step
-// blocks the tail and short runs (at most five graphs), the remainder is launched eagerly.
-static const int kGraphBlocks[2] = {50, 10};
+// cycle and the sst rotation. 50-step blocks serve long runs (one graph for the ocean: 50 = 2 x 25); what is left
+// (< 50 steps) goes out as ONE more block of the largest even length - a run of n steps is n / 50 + 1 graph
+// launches and at most one eager step (round 2 cut the tail into 10-step blocks: two replays for the driver's
+// 20-step window, each paying the ~10-16 us host-side floor of a replay).  The cache is bounded: a caller
+// that asks for ever new block lengths / phases evicts everything once kMaxGraphs is reached.
+static const int kGraphBlock50 = 50;
+static const size_t kMaxGraphs = 96;
 
 static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
   const int phase = (s0 - 1) % c->avg_period;
@@ -1772,6 +1779,11 @@ static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
   if (it != c->graphs.end()) {
     *out = it->second;
     return 0;
+  }
+  if (c->graphs.size() >= kMaxGraphs) {
+    HIPCHECK(hipStreamSynchronize(c->stream)); // replays of the graphs about to be destroyed may still be queued
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
   }
   hipGraph_t graph;
   const int ip0 = c->ip, iq0 = c->iq, is0 = c->oml.is, ism0 = c->oml.ism;
@@ -1788,6 +1800,8 @@ static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
   hipGraphExec_t exec;
   HIPCHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   HIPCHECK(hipGraphDestroy(graph));
+  // (the first replay of a fresh executable graph otherwise pays for its upload inside the caller's window)
+  if (hipGraphUpload(exec, c->stream) != hipSuccess) (void)hipGetLastError();
   c->graphs[key] = exec;
   *out = exec;
   return 0;
@@ -1797,16 +1811,14 @@ static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
 static int steps_impl(qgcm_hip_ctx *c, int s0, int n, bool dry) {
   int s = s0;
   const int is0 = c->oml.is, ism0 = c->oml.ism;
-  for (int b = 0; b < 2 && !c->profiling; ++b) {
-    const int B = kGraphBlocks[b];
-    while (n >= B) {
-      hipGraphExec_t ge;
-      if (get_graph(c, s, B, &ge)) return 1;
-      if (!dry) HIPCHECK(hipGraphLaunch(ge, c->stream));
-      s += B;
-      n -= B;
-      if (c->oml.on) oml_rotate(c, B); // the p and q rotations are back where they started, sst has moved on
-    }
+  while (!c->profiling && n >= 2) {
+    const int B = n >= kGraphBlock50 ? kGraphBlock50 : (n & ~1);
+    hipGraphExec_t ge;
+    if (get_graph(c, s, B, &ge)) return 1;
+    if (!dry) HIPCHECK(hipGraphLaunch(ge, c->stream));
+    s += B;
+    n -= B;
+    if (c->oml.on) oml_rotate(c, B); // the p and q rotations are back where they started, sst has moved on
   }
   if (dry) {
     c->oml.is = is0;
@@ -2431,6 +2443,17 @@ extern "C" int qgcm_hip_slab_steps(qgcm_hip_handle c, int s0, int n) {
   for (; n > 0; --n, ++s)
     if (slab_step(c, s)) return 1;
   return slab_join(c);
+}
+
+// Instantiate (and upload) the graphs qgcm_hip_steps(s0, n) will replay, without running anything: a caller that
+// times a window with its own clock calls this first, so that capture + instantiation stay outside the window.
+extern "C" int qgcm_hip_prepare_steps(qgcm_hip_handle c, int s0, int n) {
+  if (check_ready(c, "qgcm_hip_prepare_steps")) return 1;
+  if (!c->whole) QG_FAIL("qgcm_hip_prepare_steps: this handle is a y-slab");
+  if (s0 < 1 || n < 0) QG_FAIL("qgcm_hip_prepare_steps: bad step range");
+  if (steps_impl(c, s0, n, true)) return 1;
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) {

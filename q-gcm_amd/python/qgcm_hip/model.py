@@ -270,6 +270,12 @@ class OceanModel:
         self.step_index = s0 + int(n)
         return ms.value
 
+    def prepare_steps(self, n, s0=None):
+        """Build the HIP graphs steps(n, s0) will replay (nothing runs): keeps graph capture / instantiation out of a
+        window the caller times with its own clock."""
+        s0 = self.step_index if s0 is None else int(s0)
+        check(self.L.qgcm_hip_prepare_steps(self.h, s0, int(n)))
+
     def profile_steps(self, n, s0=None):
         """Per-kernel HIP-event totals over n eagerly launched steps:
         {name: (total_ms, launches)}."""

@@ -12,7 +12,11 @@ NSTEPS = 120
 # UNMODIFIED reference run with 1 vs 5 OpenMP threads (different summation order in xintp) differs by 1.8e-3 in po
 # after 30 ocean steps and 5e-4 after 120, while 2 vs 1 threads stay identical for 30 steps - hence one tight
 # single-step comparison and one loose long one for that case.
-RUNS = {"box_tiny": ((120, 1e-9),), "cyc_tiny": ((120, 1e-9),), "cpl_tiny": ((1, 1e-12), (120, 2e-2))}
+# Round 3 pins the coupled ocean half before chaotic growth sets in: after ONE ocean step from radiative balance the
+# ocean is still at rest (po = pom = 0 on both sides), so that case checks the atmosphere and the mixed layers only;
+# the 4- and 30-step runs go through qgostep / ocinvq / ocqbdy + oml with a moving ocean (one OpenMP thread: bitwise
+# reproducible for both executables).
+RUNS = {"box_tiny": ((120, 1e-9),), "cyc_tiny": ((120, 1e-9),), "cpl_tiny": ((1, 1e-12), (4, 1e-9), (30, 1e-6), (120, 2e-2))}
 # OpenMP threads of the host code (golden generation and test alike).  The coupled reference is NOT run-to-run
 # reproducible with two threads: two runs of the unmodified q-gcm_ref on the same case differ in pa / ast after ONE
 # ocean step (thread-order dependent sums in xforc / aml, amplified by the nearly singular barotropic zonal-mean mode

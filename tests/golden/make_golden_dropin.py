@@ -4,7 +4,7 @@
 written by dropin/make_case.py, and its final restart dump `out/last.day` (SUBROUTINE resave, src/q-gcm.F:3053-3088)
 is stored as tests/golden/dropin_<cfg>_lastday.bin.  Build container only.
 
-    python tests/golden/make_golden_dropin.py
+    python tests/golden/make_golden_dropin.py [cfg ...] [--force]
 """
 import os
 import shutil
@@ -18,10 +18,15 @@ DROP = os.path.join(ROOT, "q-gcm_amd", "fortran", "dropin")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from dropin_cases import CASES, RUNS, THREADS, golden_name, prepare_case  # noqa: E402
 
+only = sys.argv[1:]   # optional: configurations to (re)generate; existing vectors of the others are kept
 for cfg, (dims, mode) in CASES.items():
+    if only and cfg not in only:
+        continue
     subprocess.check_call([os.path.join(DROP, "build_dropin.sh"), cfg] + [str(x) for x in dims] + [mode],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for nsteps, _ in RUNS[cfg]:
+      if only and os.path.exists(os.path.join(HERE, golden_name(cfg, nsteps))) and "--force" not in only:
+          continue
       with tempfile.TemporaryDirectory() as d:
         prepare_case(cfg, d, nsteps)
         exe = os.path.join(ROOT, "q-gcm_amd", "fortran", "_dropin", cfg, "q-gcm_ref")

@@ -63,7 +63,13 @@ def test_patch_script_finds_every_edit_point():
 def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_path):
     exe = exe_path(cfg, "hip")
     if not os.path.exists(exe):
-        pytest.skip("drop-in executable not built (q-gcm_amd/fortran/dropin/build_dropin.sh needs /root/reference)")
+        # Row (b) of SURVEY 8 rests on this test: a GPU box whose snapshot lacks the executables must not show green.
+        # They are built by __graft_entry__.build() in the build container (make check_dropin needs /root/reference)
+        # and travel with the snapshot; only an explicit opt-out turns their absence into a skip.
+        if os.environ.get("QGCM_SKIP_DROPIN") == "1":
+            pytest.skip("drop-in executable not built and QGCM_SKIP_DROPIN=1")
+        pytest.fail("drop-in executable %s is missing: run __graft_entry__.build() where /root/reference is mounted "
+                    "(q-gcm_amd/fortran/dropin/build_dropin.sh), or set QGCM_SKIP_DROPIN=1 to skip knowingly" % exe)
     mode = CASES[cfg][1]
     d = str(tmp_path)
     prepare_case(cfg, d, nsteps)
@@ -77,7 +83,14 @@ def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_p
     assert got["tyrs"] == ref["tyrs"]
     # ocean steps from rest under wind (zero IC) / from radiative balance (coupled): free-running comparison
     # (tolerances: dropin_cases.RUNS)
-    for k in ("po", "pom", "sst", "sstm") + (("pa", "pam", "ast", "astm", "hmixa", "hmixam") if mode == "coupled" else ()):
+    keys = ("po", "pom", "sst", "sstm") + (("pa", "pam", "ast", "astm", "hmixa", "hmixam") if mode == "coupled" else ())
+    errs = {k: relerr(got[k], ref[k]) for k in keys}
+    try:  # the measured differences, for the record (tolerances in dropin_cases.RUNS are calibrated against them)
+        with open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "dropin_errors.log"), "a") as f:
+            f.write("%s %d steps: %s\n" % (cfg, nsteps, " ".join("%s=%.2e" % kv for kv in errs.items())))
+    except OSError:
+        pass
+    for k in keys:
         if nsteps > 1:   # (after one step from radiative balance the ocean is still at rest: po = pom = 0 in both)
             assert np.abs(ref[k]).max() > 0, k
-        assert relerr(got[k], ref[k]) < tol, (k, relerr(got[k], ref[k]))
+        assert errs[k] < tol, (k, errs)

@@ -13,12 +13,17 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("name,halo,extra", [("box_small", "allgather", ""), ("box_small", "p2p", ""), ("box_med", "allgather", ""),
-                                             ("cyc_med", "allgather", ""), ("cyc_small", "p2p", ""),
-                                             ("box_small", "p2p", "oml"), ("cyc_small", "allgather", "oml"),
-                                             ("box_med", "p2p", "early"), ("box_med", "allgather", "early")])
+MP_CASES = [("box_small", "allgather", ""), ("box_small", "p2p", ""), ("box_med", "allgather", ""),
+            ("cyc_med", "allgather", ""), ("cyc_small", "p2p", ""),
+            ("box_small", "p2p", "oml"), ("cyc_small", "allgather", "oml"),
+            ("box_med", "p2p", "early"), ("box_med", "allgather", "early")]
+
+
+@pytest.mark.parametrize("name,halo,extra", MP_CASES)
 def test_three_processes_one_slab_each(name, halo, extra):
-    port = 29600 + (hash((name, halo, extra)) % 300)
+    # one rendezvous port per case, fixed by the case's position (Python's hash() of a str is randomised per process:
+    # two cases could land on one port)
+    port = 29600 + 7 * MP_CASES.index((name, halo, extra))
     nproc = "2" if extra == "early" else "3"  # (early: slabs of at least three 16-row tile rows - 97 rows make two)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", nproc, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "mp_slab_worker.py"), name, halo] + ([extra] if extra else [])
