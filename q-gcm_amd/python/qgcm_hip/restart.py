@@ -57,7 +57,9 @@ def read_restart(path, cfg, coupled=False):
     return out
 
 
-def write_restart(path, cfg, tyrs, po, pom, sst=None, sstm=None, ast=None, astm=None, hmixa=None, hmixam=None):
+def write_restart(path, cfg, tyrs, po, pom, sst=None, sstm=None, ast=None, astm=None, hmixa=None, hmixam=None,
+                  pa=None, pam=None):
+    """pa, pam given: the dump of a coupled build (record [pa, pam] after [po, pom])."""
     zT, zA = np.zeros((cfg.nxto, cfg.nyto)), np.zeros((cfg.nxta, cfg.nyta))
     d = lambda x, z: z if x is None else x
     for x, sh in ((po, (cfg.nxpo, cfg.nypo, cfg.nlo)), (pom, (cfg.nxpo, cfg.nypo, cfg.nlo))):
@@ -66,6 +68,8 @@ def write_restart(path, cfg, tyrs, po, pom, sst=None, sstm=None, ast=None, astm=
     with open(path, "wb") as f:
         _put(f, np.array([tyrs], dtype=np.float64))
         _put(f, po, pom)
+        if pa is not None:
+            _put(f, pa, pam)
         _put(f, d(sst, zT), d(sstm, zT))
         _put(f, d(ast, zA), d(astm, zA))
         _put(f, d(hmixa, zA), d(hmixam, zA))

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
 DROP = os.path.join(ROOT, "q-gcm_amd", "fortran", "dropin")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from dropin_cases import CASES, RUNS, THREADS, golden_name, prepare_case  # noqa: E402
+from dropin_cases import CASES, RUNS, RUNS_RESTART, THREADS, golden_name, prepare_case  # noqa: E402
 
 only = sys.argv[1:]   # optional: configurations to (re)generate; existing vectors of the others are kept
 for cfg, (dims, mode) in CASES.items():
@@ -24,15 +24,15 @@ for cfg, (dims, mode) in CASES.items():
         continue
     subprocess.check_call([os.path.join(DROP, "build_dropin.sh"), cfg] + [str(x) for x in dims] + [mode],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for nsteps, _ in RUNS[cfg]:
-      if only and os.path.exists(os.path.join(HERE, golden_name(cfg, nsteps))) and "--force" not in only:
+    for nsteps, rst in [(n, False) for n, _ in RUNS[cfg]] + [(n, True) for n, _ in RUNS_RESTART.get(cfg, ())]:
+      if only and os.path.exists(os.path.join(HERE, golden_name(cfg, nsteps, rst))) and "--force" not in only:
           continue
       with tempfile.TemporaryDirectory() as d:
-        prepare_case(cfg, d, nsteps)
+        prepare_case(cfg, d, nsteps, rst)
         exe = os.path.join(ROOT, "q-gcm_amd", "fortran", "_dropin", cfg, "q-gcm_ref")
         env = dict(os.environ, OMP_NUM_THREADS=str(THREADS[cfg]), OMP_STACKSIZE="512M")
         log = subprocess.run("ulimit -s unlimited; exec %s" % exe, shell=True, cwd=d, env=env, stdout=subprocess.PIPE,
                              stderr=subprocess.STDOUT, text=True)
         assert log.returncode == 0 and "End of run" in log.stdout, log.stdout[-2000:]
-        shutil.copy(os.path.join(d, "out", "last.day"), os.path.join(HERE, golden_name(cfg, nsteps)))
-        print("wrote %s (%d ocean steps)" % (golden_name(cfg, nsteps), nsteps))
+        shutil.copy(os.path.join(d, "out", "last.day"), os.path.join(HERE, golden_name(cfg, nsteps, rst)))
+        print("wrote %s (%d ocean steps%s)" % (golden_name(cfg, nsteps, rst), nsteps, ", from the eddy restart" if rst else ""))

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from common import GOLDEN, relerr
-from dropin_cases import CASES, DROP, RUNS, THREADS, exe_path, golden_name, prepare_case
+from dropin_cases import CASES, DROP, RUNS, RUNS_RESTART, THREADS, exe_path, golden_name, prepare_case
 from qgcm_hip import config, restart
 
 HAVE_REF = os.path.isdir("/root/reference/src")
@@ -59,8 +59,9 @@ def test_patch_script_finds_every_edit_point():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,nsteps,tol", [(c, n, t) for c in CASES for n, t in RUNS[c]])
-def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_path):
+@pytest.mark.parametrize("cfg,nsteps,tol,rst", [(c, n, t, False) for c in CASES for n, t in RUNS[c]] +
+                         [(c, n, t, True) for c in RUNS_RESTART for n, t in RUNS_RESTART[c]])
+def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, rst, tmp_path):
     exe = exe_path(cfg, "hip")
     if not os.path.exists(exe):
         # Row (b) of SURVEY 8 rests on this test: a GPU box whose snapshot lacks the executables must not show green.
@@ -72,14 +73,14 @@ def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_p
                     "(q-gcm_amd/fortran/dropin/build_dropin.sh), or set QGCM_SKIP_DROPIN=1 to skip knowingly" % exe)
     mode = CASES[cfg][1]
     d = str(tmp_path)
-    prepare_case(cfg, d, nsteps)
+    prepare_case(cfg, d, nsteps, rst)
     env = dict(os.environ, OMP_NUM_THREADS=str(THREADS[cfg]), OMP_STACKSIZE="512M")
     r = subprocess.run("ulimit -s unlimited 2>/dev/null; exec %s" % exe, shell=True, cwd=d, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "End of run" in r.stdout, r.stdout[-3000:]
     oc = config.preset(cfg)
     got = restart.read_restart(os.path.join(d, "out", "last.day"), oc, coupled=(mode == "coupled"))
-    ref = restart.read_restart(os.path.join(GOLDEN, golden_name(cfg, nsteps)), oc, coupled=(mode == "coupled"))
+    ref = restart.read_restart(os.path.join(GOLDEN, golden_name(cfg, nsteps, rst)), oc, coupled=(mode == "coupled"))
     assert got["tyrs"] == ref["tyrs"]
     # ocean steps from rest under wind (zero IC) / from radiative balance (coupled): free-running comparison
     # (tolerances: dropin_cases.RUNS)
@@ -87,7 +88,7 @@ def test_dropin_executable_matches_the_reference_restart(cfg, nsteps, tol, tmp_p
     errs = {k: relerr(got[k], ref[k]) for k in keys}
     try:  # the measured differences, for the record (tolerances in dropin_cases.RUNS are calibrated against them)
         with open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "dropin_errors.log"), "a") as f:
-            f.write("%s %d steps: %s\n" % (cfg, nsteps, " ".join("%s=%.2e" % kv for kv in errs.items())))
+            f.write("%s %d steps%s: %s\n" % (cfg, nsteps, " (eddy restart)" if rst else "", " ".join("%s=%.2e" % kv for kv in errs.items())))
     except OSError:
         pass
     for k in keys:
