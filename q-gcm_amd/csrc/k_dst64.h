@@ -360,7 +360,11 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
   double *rowb = rowa + ldw;
   double rsa, rsb;
-  dst64_core<M>(P, rowa, rowb, has_b, Fsh[wv], W64sh[wv], lane, rsa, rsb);
+  QG_STAMP(0, 0);
+  dst64_front<M>(P, rowa, rowb, has_b, Fsh[wv], W64sh[wv], lane);
+  QG_STAMP(0, 1);
+  dst64_back<M>(Fsh[wv], W64sh[wv], lane, rsa, rsb);
+  QG_STAMP(0, 2);
   const double *raw = reinterpret_cast<const double *>(Fsh[wv]);
   constexpr int NP = N + N / 16;
   {
@@ -376,6 +380,9 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
       }
     }
   }
+  QG_STAMP(0, 3);
+  QG_STAMP_DRAIN();
+  QG_STAMP(0, 4);
   if (ROWSUM) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -550,7 +557,9 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
   // the front half, whose row loads need the registers (one wave per mode), so that the kernel keeps two waves per SIMD.
   constexpr int NT = 64 * NL, NIT = (NX - 2 + NT - 1) / NT;
   const double *rowa = P.wrk + P.g.wstride * wv + (long)(ja - 1) * ldw;
+  QG_STAMP(2, 0);
   dst64_front<M>(P, rowa, rowa + ldw, has_b, Fsh[wv], W64sh[wv], lane);
+  QG_STAMP(2, 1);
   asm volatile("" ::: "memory"); // keep the prefetch below the front half
   double oc[2][NIT][NL - 1];
 #pragma unroll
@@ -574,7 +583,9 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
     double rsa, rsb;
     dst64_back<M>(Fsh[wv], W64sh[wv], lane, rsa, rsb);
   }
+  QG_STAMP(2, 2);
   __syncthreads();
+  QG_STAMP(2, 3);
   if (CONSTR) {
 #pragma unroll
     for (int m = 1; m < NL; ++m) hc[m] = hc_sh[m];
@@ -603,6 +614,9 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       }
     }
   }
+  QG_STAMP(2, 4);
+  QG_STAMP_DRAIN();
+  QG_STAMP(2, 5);
   // wall rows of the basin (G = 1, nyg): done by the workgroup of the first / last interior row
 #pragma unroll
   for (int r = 0; r < 2; ++r) {

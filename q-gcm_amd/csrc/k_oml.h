@@ -111,7 +111,7 @@ __device__ __forceinline__ void oml_block_sums(double *v, double *sm, int tid) {
   for (int q = 0; q < NV; ++q) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off);
-    if ((tid & 63) == 0) sm[q * 4 + (tid >> 6)] = v[q];
+    if ((tid & 63) == 0 && tid < OML_NT) sm[q * 4 + (tid >> 6)] = v[q]; // (a caller may have more than OML_NT threads)
   }
   __syncthreads();
 #pragma unroll
@@ -304,12 +304,13 @@ struct QgOmlFinal {
 // one workgroup of OML_NT threads; red: 20 doubles of LDS
 __device__ __forceinline__ void oml_final_block(const QgOmlFinal &P, double *red, int tid) {
   double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int k = tid; k < P.nblkB; k += OML_NT) {
+  const int first = tid < OML_NT ? tid : (1 << 30); // threads beyond OML_NT (k_tend_stream: 384) only keep the barrier
+  for (int k = first; k < P.nblkB; k += OML_NT) {
     a[0] += P.partB[k];
     a[1] += P.partB[P.nblkB + k];
     a[2] += P.partB[2 * P.nblkB + k];
   }
-  for (int k = tid; k < P.nblkA; k += OML_NT) {
+  for (int k = first; k < P.nblkA; k += OML_NT) {
     a[3] += P.partA[P.nblkA + k];
     a[4] += P.partA[2 * P.nblkA + k];
   }

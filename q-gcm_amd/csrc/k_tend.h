@@ -210,6 +210,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   }
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= ntiles) return;
+  QG_STAMP(3, 0);
   const int i0 = (tile % gx) * TX + 1; // first global i of the tile (1-based)
   const int trow = P.trows ? P.trow0 + (tile / gx) * P.tstride : tile / gx;
   const int j0 = trow * TY + jlo; // first local row of the tile
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       }
     }
     __syncthreads();
+    QG_STAMP(3, 1 + 2 * k);
     // ---- issue the loads of layer k+1 (they fly while layer k is computed)
     if (k + 1 < NL) {
       const double *pom = P.pom + fs * (k + 1);
@@ -379,6 +381,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       dq[k][r] = val;
       if (k == NL - 1) d2bot[r] = sd2[(ly + 2) * W2 + (tx + 2)];
     }
+    QG_STAMP(3, 2 + 2 * k);
     if (k + 1 < NL) __syncthreads();
   }
 
@@ -398,4 +401,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
     }
     tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
   }
+  QG_STAMP(3, 7);
+  QG_STAMP_DRAIN();
+  QG_STAMP(3, 8);
 }

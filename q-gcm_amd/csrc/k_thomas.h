@@ -130,6 +130,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
     }
     return;
   }
+  QG_STAMP(1, 0);
   const int kk = tid % KW;
   const int c = tid / KW;
   const int lane = tid & 63, wv = tid >> 6;
@@ -236,9 +237,11 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
       D = -b[t] * D;
     }
   }
+  QG_STAMP(1, 1);
   sC[c][kk] = C;
   sD[c][kk] = D;
   __syncthreads();
+  QG_STAMP(1, 2);
   double Cs = sC[lane][wv], Ds = sD[lane][wv];
   affine_scan(Cs, Ds, lane);
   // lane 63 holds the composition of all chunks: zero-inflow end value and slab gain
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
     sIn[lane][wv] = (lane == 0) ? uin : Cprev + Dprev * uin;
   }
   __syncthreads();
+  QG_STAMP(1, 3);
   double u = sIn[c][kk];
 #pragma unroll
   for (int t = 0; t < R; ++t) {
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
   sC[c][kk] = C; // safe without a barrier: every wave read the forward maps in sC / sD before the barrier above
   sD[c][kk] = D;
   __syncthreads();
+  QG_STAMP(1, 4);
   // sweep order is last chunk first: lane l stands for chunk 63-l
   const int cr = 63 - lane;
   Cs = sC[cr][wv];
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
     sIn[cr][wv] = (lane == 0) ? vin : Cprev + Dprev * vin;
   }
   __syncthreads();
+  QG_STAMP(1, 5);
   double v = sIn[c][kk];
   double colsum = 0.0;
 #pragma unroll
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
       colsum += v;
     }
   }
+  QG_STAMP(1, 6);
   if (PHASE == 0 || PHASE == 2) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
@@ -299,6 +306,9 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
       if (kok && r < nr) wbase[off0 + (unsigned)(t * ldw)] = ft * w[t];
     }
   }
+  QG_STAMP(1, 7);
+  QG_STAMP_DRAIN();
+  QG_STAMP(1, 8);
   if (CYCA && PHASE == 0 && P.ybnd && k == 0) { // (cyclic instantiation only: the box kernel has no register to spare)
     // cyclic constraints: the zonal-mean solution next to the two zonal boundaries (rows 2 and nypo-1) goes to a side
     // buffer, so that part B of the constraint algebra does not have to read wrk - which the in-place inverse rows of

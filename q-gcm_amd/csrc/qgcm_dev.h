@@ -15,6 +15,23 @@
 #include "../../include/qgcm_hip.h"
 
 #define QG_MAXL QGCM_HIP_MAXL
+
+// In-kernel phase stamps (development builds only, -DQG_STAMPS: scratch/stamps.py): thread 0 of every workgroup
+// records the constant 100 MHz wall clock at phase boundaries; never compiled into the product library.
+#ifdef QG_STAMPS
+#define QG_NSTAMP 10
+#define QG_STAMP_BLOCKS 4096
+__device__ long long qg_stamps[4][QG_STAMP_BLOCKS][QG_NSTAMP];
+#define QG_STAMP(kern, i)                                                                   \
+  do {                                                                                      \
+    const unsigned qg_b = blockIdx.x + gridDim.x * blockIdx.y;                              \
+    if (threadIdx.x == 0 && qg_b < QG_STAMP_BLOCKS) qg_stamps[kern][qg_b][i] = wall_clock64(); \
+  } while (0)
+#define QG_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define QG_STAMP(kern, i) do { } while (0)
+#define QG_STAMP_DRAIN() do { } while (0)
+#endif
 #define QG_MAXFAC 24
 
 // scalars that live on the device between kernels (MODULE ochomog state)

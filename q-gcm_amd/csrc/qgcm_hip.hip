@@ -13,6 +13,7 @@
 
 #include "qgcm_dev.h"
 #include "k_tend.h"
+#include "k_tend_stream.h"
 #include "k_dst.h"
 #include "k_fft3.h"
 // the row lengths with a three-stage plan: NAtl 1 km (4800), SOcn 5 km (4608), and two more for the tests
@@ -91,6 +92,7 @@ struct qgcm_hip_ctx {
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
+  bool tend_stream;       // the register-streaming tendency kernel (k_tend_stream.h); QGCM_HIP_TEND_TILES=1: the LDS-tile kernel (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
   hipError_t timer_err = hipSuccess;
@@ -260,6 +262,8 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     c->no_fused_unpack = f && f[0] == '1';
     const char *fc = getenv("QGCM_HIP_NO_FUSED_CONSTR");
     c->no_fused_constr = fc && fc[0] == '1';
+    const char *tt = getenv("QGCM_HIP_TEND_STREAM");
+    c->tend_stream = tt && tt[0] == '1';
   }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
@@ -800,6 +804,29 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   }
   QgOmlFinal F;
   fill_oml_final(c, F, oml_final && c->oml.on && part != TEND_OUTER);
+  if (c->tend_stream) {
+    // the register-streaming kernel (k_tend_stream.h): units of (58-column strip) x (16-row tile row), all layers
+    const TsTiling Ts = g.cyc ? ts_tiling<true>(g) : ts_tiling<false>(g);
+    const int nunits = Ts.gx * (part == TEND_ALL ? Ts.gy : P.trows);
+    const int nex = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : Ts.nedge);
+    KTimer t(c, KN_TEND);
+#define QG_TENDS(NLV)                                                                                         \
+  {                                                                                                           \
+    const int nwg = (nunits + TsCfg<NLV>::SPW - 1) / TsCfg<NLV>::SPW;                                         \
+    const dim3 grid(8 * ((nwg + 7) / 8) + nex);                                                               \
+    if (g.cyc) hipLaunchKernelGGL((k_tend_stream<NLV, true>), grid, dim3(TsCfg<NLV>::NT), 0, c->stream, P, S, F); \
+    else hipLaunchKernelGGL((k_tend_stream<NLV, false>), grid, dim3(TsCfg<NLV>::NT), 0, c->stream, P, S, F);       \
+  }
+    switch (g.nl) {
+      case 2: QG_TENDS(2); break;
+      case 3: QG_TENDS(3); break;
+      case 4: QG_TENDS(4); break;
+      default: QG_FAIL("k_tend_stream: unsupported nlo");
+    }
+#undef QG_TENDS
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
   const int nextra = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : T.nedge);
   dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
@@ -2537,3 +2564,13 @@ extern "C" int qgcm_hip_copy_bandwidth(qgcm_hip_handle c, size_t bytes, int reps
 }
 
 extern "C" void *qgcm_hip_stream(qgcm_hip_handle c) { return c ? (void *)c->stream : nullptr; }
+
+#ifdef QG_STAMPS
+// development builds only (scratch/stamps.py): the phase stamps of the last launch of each instrumented kernel
+extern "C" int qgcm_hip_debug_stamps(long long *out, size_t nbytes) {
+  if (nbytes > sizeof(qg_stamps)) nbytes = sizeof(qg_stamps);
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(qg_stamps), nbytes, 0, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
