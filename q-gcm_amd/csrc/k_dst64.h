@@ -232,37 +232,63 @@ __device__ __forceinline__ void dst64_back(cplx *F, const cplx *W64, int lane, d
   constexpr int N = 64 * M, n = N - 1, NS2 = n / 2;
   double *raw = reinterpret_cast<double *>(F); // output rows a, b (padded)
   // ---- (2a) radix-8 over a (n2 = 8a + b), twiddle W64^(b*c), in place -------
+  // (A wave has few neighbours to hide its LDS round trips behind - 1.4 waves per SIMD at NAtl 5 km - so every stage
+  //  first asks for ALL it reads, of both rounds, then computes, then writes: round 2 rewrote these loops after the
+  //  ISA showed read x8 -> wait -> compute -> write x8 per round, each round trip fully exposed.)
   constexpr int NBF = M * 8;
+  constexpr int NRD = (NBF + 63) / 64;
+  {
+    cplx x[NRD][8];
+    cplx tw[NRD][7];
 #pragma unroll
-  for (int rd = 0; rd < (NBF + 63) / 64; ++rd) {
-    const int id = lane + 64 * rd;
-    if (id < NBF) {
-      const int k1 = id >> 3, b = id & 7;
-      cplx *row = F + k1 * D64_ROW + b;
-      cplx x[8];
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int id = lane + 64 * rd;
+      const int idc = id < NBF ? id : NBF - 1; // (clamped: idle lanes of the last round read valid rows, write nothing)
+      const int k1 = idc >> 3, b = idc & 7;
+      const cplx *row = F + k1 * D64_ROW + b;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = row[9 * q];
-      dft8(x);
+      for (int q = 0; q < 8; ++q) x[rd][q] = row[9 * q];
 #pragma unroll
-      for (int c = 1; c < 8; ++c) x[c] = cmul(x[c], W64[b * c]);
+      for (int c = 1; c < 8; ++c) tw[rd][c - 1] = W64[b * c];
+    }
 #pragma unroll
-      for (int c = 0; c < 8; ++c) row[9 * c] = x[c];
+    for (int rd = 0; rd < NRD; ++rd) {
+      dft8(x[rd]);
+#pragma unroll
+      for (int c = 1; c < 8; ++c) x[rd][c] = cmul(x[rd][c], tw[rd][c - 1]);
+    }
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int id = lane + 64 * rd;
+      if (id < NBF) {
+        cplx *row = F + (id >> 3) * D64_ROW + (id & 7);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[9 * c] = x[rd][c];
+      }
     }
   }
   wave_lds_sync();
   // ---- (2b) radix-8 over b for fixed c: positions 9c + b -> 9c + d (k2 = c + 8d)
+  {
+    cplx x[NRD][8];
 #pragma unroll
-  for (int rd = 0; rd < (NBF + 63) / 64; ++rd) {
-    const int id = lane + 64 * rd;
-    if (id < NBF) {
-      const int k1 = id >> 3, c = id & 7;
-      cplx *row = F + k1 * D64_ROW + 9 * c;
-      cplx x[8];
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int id = lane + 64 * rd;
+      const int idc = id < NBF ? id : NBF - 1;
+      const cplx *row = F + (idc >> 3) * D64_ROW + 9 * (idc & 7);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = row[q];
-      dft8(x);
+      for (int q = 0; q < 8; ++q) x[rd][q] = row[q];
+    }
 #pragma unroll
-      for (int d = 0; d < 8; ++d) row[d] = x[d];
+    for (int rd = 0; rd < NRD; ++rd) dft8(x[rd]);
+#pragma unroll
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int id = lane + 64 * rd;
+      if (id < NBF) {
+        cplx *row = F + (id >> 3) * D64_ROW + 9 * (id & 7);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) row[d] = x[rd][d];
+      }
     }
   }
   wave_lds_sync();
@@ -277,23 +303,32 @@ __device__ __forceinline__ void dst64_back(cplx *F, const cplx *W64, int lane, d
   int bk1 = (N - k0) % M, bk2 = (N - k0) / M;
   double rea[CH], ima[CH], reb[CH], imb[CH];
   double suma = 0.0, sumb = 0.0;
+  {
+    // all reads of the spectrum first (their LDS positions do not depend on data), then the arithmetic
+    cplx z1[CH], z2[CH];
 #pragma unroll
-  for (int t = 0; t < CH; ++t) {
-    const int k = k0 + t;
-    const int za = ak1 * D64_ROW + 9 * (ak2 & 7) + (ak2 >> 3);
-    const int zb = bk1 * D64_ROW + 9 * (bk2 & 7) + (bk2 >> 3);
-    if (++ak1 == M) { ak1 = 0; ++ak2; }
-    if (--bk1 < 0) { bk1 = M - 1; --bk2; }
-    if (k <= K) {
-      cplx z1 = F[za], z2 = F[zb];
-      rea[t] = 0.5 * (z1.x + z2.x);
-      ima[t] = 0.5 * (z1.y - z2.y);
-      reb[t] = 0.5 * (z1.y + z2.y);
-      imb[t] = -0.5 * (z1.x - z2.x);
-      suma += rea[t];
-      sumb += reb[t];
-    } else {
-      rea[t] = ima[t] = reb[t] = imb[t] = 0.0;
+    for (int t = 0; t < CH; ++t) {
+      const int za = ak1 * D64_ROW + 9 * (ak2 & 7) + (ak2 >> 3);
+      const int zb = bk1 * D64_ROW + 9 * (bk2 & 7) + (bk2 >> 3);
+      if (++ak1 == M) { ak1 = 0; ++ak2; }
+      if (--bk1 < 0) { bk1 = M - 1; --bk2; }
+      const bool ok = k0 + t <= K;
+      z1[t] = F[ok ? za : 0];
+      z2[t] = F[ok ? zb : 0];
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {
+      const int k = k0 + t;
+      if (k <= K) {
+        rea[t] = 0.5 * (z1[t].x + z2[t].x);
+        ima[t] = 0.5 * (z1[t].y - z2[t].y);
+        reb[t] = 0.5 * (z1[t].y + z2[t].y);
+        imb[t] = -0.5 * (z1[t].x - z2[t].x);
+        suma += rea[t];
+        sumb += reb[t];
+      } else {
+        rea[t] = ima[t] = reb[t] = imb[t] = 0.0;
+      }
     }
   }
   const cplx z0 = F[0];
@@ -368,15 +403,23 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
   const double *raw = reinterpret_cast<const double *>(Fsh[wv]);
   constexpr int NP = N + N / 16;
   {
-    double2 *ga = reinterpret_cast<double2 *>(rowa);
-    double2 *gb = reinterpret_cast<double2 *>(rowb);
+    constexpr int NU = (N / 2 + 63) / 64;
+    // all LDS reads of the two output rows first, then the global stores (one exposed LDS round trip instead of 2 NU)
+    double2 oa[NU], ob[NU];
 #pragma unroll
-    for (int u = 0; u < (N / 2 + 63) / 64; ++u) {
-      int t = lane + 64 * u;
-      if (t < N / 2) {
-        const int i = 2 * t + ((2 * t) >> 4); // 2t and 2t+1 share a 16-group: consecutive after padding
-        ga[t] = double2{raw[i], raw[i + 1]};
-        if (has_b) gb[t] = double2{raw[NP + i], raw[NP + i + 1]};
+    for (int u = 0; u < NU; ++u) {
+      const int t = lane + 64 * u;
+      const int tc = t < N / 2 ? t : N / 2 - 1;
+      const int i = 2 * tc + ((2 * tc) >> 4); // 2t and 2t+1 share a 16-group: consecutive after padding
+      oa[u] = double2{raw[i], raw[i + 1]};
+      ob[u] = double2{raw[NP + i], raw[NP + i + 1]};
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int t = lane + 64 * u;
+      if (t < N / 2) { // (write-through: qgcm_dev.h)
+        qg_store16_wt(rowa + 2 * t, oa[u].x, oa[u].y);
+        if (has_b) qg_store16_wt(rowb + 2 * t, ob[u].x, ob[u].y);
       }
     }
   }
@@ -516,10 +559,21 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
 #pragma unroll
       for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
       msg_p(gw, gj, pl);
-      if (BDY) {
+      if (BDY || side == 0) {
         double pin[NL];
         point(gn, gj, r, w.ocn[r], pin);
-        bdy_q(o, pl, pin, w.byw[r], w.ddw[r], gw, gj);
+        if (BDY) bdy_q(o, pl, pin, w.byw[r], w.ddw[r], gw, gj);
+        if (side == 0) {
+          // column 2: the interior columns are combined in 16-byte pairs (3,4) .. (nx-2, nx-1) - this one is left over
+          const long on = (long)(gj - 1) * U.g.ldx + (gn - 1);
+#pragma unroll
+          for (int k = 0; k < NL; ++k) U.pnew[fs * k + on] = pin[k];
+          msg_p(gn, gj, pin);
+          if (HALO && ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi))) {
+#pragma unroll
+            for (int k = 0; k < NL; ++k) msg_q(gn, gj, k, B.qo[fs * k + on]);
+          }
+        }
       }
     }
   };
@@ -555,22 +609,25 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
   // waves of modes 0 (W) and 1 (E).
   // Everything the combine step reads from global memory is requested before the back half of the transform - after
   // the front half, whose row loads need the registers (one wave per mode), so that the kernel keeps two waves per SIMD.
-  constexpr int NT = 64 * NL, NIT = (NX - 2 + NT - 1) / NT;
+  constexpr int NT = 64 * NL, NPAIR = (NX - 3) / 2, NIT = (NPAIR + NT - 1) / NT;
   const double *rowa = P.wrk + P.g.wstride * wv + (long)(ja - 1) * ldw;
   QG_STAMP(2, 0);
   dst64_front<M>(P, rowa, rowa + ldw, has_b, Fsh[wv], W64sh[wv], lane);
   QG_STAMP(2, 1);
   asm volatile("" ::: "memory"); // keep the prefetch below the front half
-  double oc[2][NIT][NL - 1];
+  // (column pairs (3,4), (5,6) .. (nx-2, nx-1): 16-byte aligned in the field arrays - 16-byte loads of ochom and
+  //  16-byte write-through stores of the new po; column 2 goes with the W wall column)
+  double2 oc[2][NIT][NL - 1];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int gi = 2 + tid + it * NT;
-      const bool ok = gi <= NX - 1 && (r == 0 || has_b);
+      const int q = tid + it * NT;
+      const int gi = 3 + 2 * q;
+      const bool ok = q < NPAIR && (r == 0 || has_b);
       const long o = (long)(ja + r - 1) * U.g.ldx + (gi - 1);
 #pragma unroll
-      for (int m = 1; m < NL; ++m) oc[r][it][m - 1] = ok ? U.ochom[fs * (m - 1) + o] : 0.0;
+      for (int m = 1; m < NL; ++m) oc[r][it][m - 1] = ok ? *reinterpret_cast<const double2 *>(U.ochom + fs * (m - 1) + o) : double2{0.0, 0.0};
     }
   const bool wallcol = !CONSTR && (lane == 0 && wv < 2);
   WallPre wpre;
@@ -600,17 +657,28 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
     const int gj = ja + r;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int gi = 2 + tid + it * NT;
-      if (gi > nx - 1) break;
+      const int q = tid + it * NT;
+      if (q >= NPAIR) break;
+      const int gi = 3 + 2 * q;
       const long o = (long)(gj - 1) * U.g.ldx + (gi - 1);
-      double pl[NL];
-      point(gi, gj, r, oc[r][it], pl);
+      double oca[NL - 1], ocb[NL - 1], pla[NL], plb[NL];
 #pragma unroll
-      for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
-      msg_p(gi, gj, pl);
+      for (int m = 1; m < NL; ++m) {
+        oca[m - 1] = oc[r][it][m - 1].x;
+        ocb[m - 1] = oc[r][it][m - 1].y;
+      }
+      point(gi, gj, r, oca, pla);
+      point(gi + 1, gj, r, ocb, plb);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) qg_store16_wt(U.pnew + fs * k + o, pla[k], plb[k]);
+      msg_p(gi, gj, pla);
+      msg_p(gi + 1, gj, plb);
       if (HALO && ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi))) { // interior columns of the q row: set by k_tend
 #pragma unroll
-        for (int k = 0; k < NL; ++k) msg_q(gi, gj, k, B.qo[fs * k + o]);
+        for (int k = 0; k < NL; ++k) {
+          msg_q(gi, gj, k, B.qo[fs * k + o]);
+          msg_q(gi + 1, gj, k, B.qo[fs * k + o + 1]);
+        }
       }
     }
   }

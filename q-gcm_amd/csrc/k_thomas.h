@@ -300,10 +300,30 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
   }
   QG_STAMP(1, 6);
   if (PHASE == 0 || PHASE == 2) {
+    if (R % 2 == 0) {
+      // 16-byte write-through stores (qgcm_dev.h: all of this kernel's stores come at its very end): the lanes of two
+      // neighbouring wavenumbers swap one value per pair of rows, the even lane then stores row t for both, the odd
+      // lane row t + 1 (columns k - 1, k).  A column past nk is a padding column of the row (ldw = nk rounded up).
+      const bool odd = (kk & 1) != 0;
+      const bool pok = odd ? (k - 1 < P.g.nk) : kok; // the pair's first column exists
+      double *cbase = wbase + (odd ? off0 - 1 : off0);
 #pragma unroll
-    for (int t = 0; t < R; ++t) {
-      int r = r0 + t;
-      if (kok && r < nr) wbase[off0 + (unsigned)(t * ldw)] = ft * w[t];
+      for (int t = 0; t < R; t += 2) {
+        const double mine0 = ft * w[t], mine1 = ft * w[t + 1];
+        const double give = odd ? mine0 : mine1;
+        int lo = __double2loint(give), hi = __double2hiint(give);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, true);
+        const double got = __hiloint2double(hi, lo);
+        const int r = r0 + t + (odd ? 1 : 0);
+        if (pok && r < nr) qg_store16_wt(cbase + (unsigned)((t + (odd ? 1 : 0)) * ldw), odd ? got : mine0, odd ? mine1 : got);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        int r = r0 + t;
+        if (kok && r < nr) wbase[off0 + (unsigned)(t * ldw)] = ft * w[t];
+      }
     }
   }
   QG_STAMP(1, 7);

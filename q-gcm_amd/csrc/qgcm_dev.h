@@ -34,6 +34,28 @@ __device__ long long qg_stamps[4][QG_STAMP_BLOCKS][QG_NSTAMP];
 #endif
 #define QG_MAXFAC 24
 
+// 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1).  Why: a kernel whose stores all come at its end leaves its
+// whole output dirty in the XCDs' L2s, and the end-of-kernel write-back of those lines runs AFTER the last wave, in
+// series with everything (in-kernel stamps, NAtl 5 km: 3.4 us between the forward rows and the Thomas sweep, 5.7 us
+// between the sweep and the inverse rows, for 22 MB each).  Written through, the bytes leave while other waves still
+// compute and the next kernel finds them in the Infinity Cache: forward rows + sweep -2.7 us per step (A/B,
+// profiles/r3_*).  Only the 16-byte form pays: 8-byte sc1 stores go out as one fabric write per lane
+// (MI355X_MICROARCH.md, "stores of each flavour"; measured: no gain).  Inline asm because HIP has no 16-byte
+// agent-scope store; the compiler does not count it in vmcnt, which only makes its own waits more conservative -
+// nothing in these kernels reads what they have stored.  p must be 16-byte aligned.  tests: every parity test of the
+// Helmholtz path runs through these stores (a missing hazard pad showed as 1e-2 errors in scattered column pairs).
+__device__ __forceinline__ void qg_store16_wt(double *p, double a, double b) {
+#ifdef QG_WT_PLAIN // (A/B builds: the same pairing with plain cached stores)
+  *reinterpret_cast<double2 *>(p) = double2{a, b};
+#else
+  typedef double qg_v2d __attribute__((ext_vector_type(2)));
+  const qg_v2d v = {a, b};
+  // (s_nop 1: the hazard pad hipcc would put behind a 16-byte store of its own - without it the next instruction may
+  //  overwrite the data registers before the store has read them; cdna_hip_programming.md 5.7, item 1)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 // scalars that live on the device between kernels (MODULE ochomog state)
 struct QgScalars {
   double dpioc[QG_MAXL], dpiocp[QG_MAXL], xon[QG_MAXL];
