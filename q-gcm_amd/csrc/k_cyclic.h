@@ -316,10 +316,12 @@ template <int NL, bool BDY>
 __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, const QgBdyParams B) {
   const int nx = P.g.nx, ny = P.g.ny, nxt = P.g.nxt;
   const int nyg = P.g.nyg, joff = P.g.joff;
-  const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const int gi0 = blockIdx.x * blockDim.x + threadIdx.x + 1;
   const int gj = blockIdx.y + P.g.jlo; // owned rows only (the halo rows of a y-slab come with the exchange)
-  if (gi > nx || gj > P.g.jhi) return;
-  const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
+  if (gj > P.g.jhi) return;
+  const bool valid = gi0 <= nx;
+  const int gi = valid ? gi0 : nx; // (lanes past the row keep the wave whole for the pair stores; they write nothing)
+  const long o = (long)(gj - 1) * P.g.ldx + (gi0 - 1);
   const int ci = (gi > nxt) ? 0 : gi - 1; // column nx is column 1
   auto point = [&](int jrow, double *pl) {
     const bool inner = (jrow + joff >= 2 && jrow + joff <= nyg - 1);
@@ -342,7 +344,8 @@ __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, cons
   double pl[NL];
   point(gj, pl);
 #pragma unroll
-  for (int k = 0; k < NL; ++k) P.pnew[P.g.fstride * k + o] = pl[k];
+  for (int k = 0; k < NL; ++k) qg_pair_store_wt(P.pnew + P.g.fstride * k + o, pl[k], valid); // (qgcm_dev.h)
+  if (!valid) return;
   const int G = gj + joff;
   if (BDY && (G == 1 || G == nyg)) {
     double pin[NL];

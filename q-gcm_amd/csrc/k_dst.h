@@ -377,13 +377,15 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   }
   __syncthreads();
   if (single) {
+    // elements 2t, 2t+1 as one 16-byte write-through store (qgcm_dev.h; N is even here, and element n = N - 1 of the
+    // last pair is the padding column of the row): b[2t] = Z[t].y (Z[0].x for t = 0), b[2t+1] = Z[t+1].x, row b alike
+    // from Z[N-t], Z[N-t-1]
 #pragma unroll
-    for (int i = tid; i < n; i += NT) {
-      const int k = (i + 1) >> 1;
-      const cplx za = Z[PLAN::pos_out(k)], zb = Z[PLAN::pos_out((N - k) % N)];
-      const bool first = (i == 0) || (i & 1);
-      rowa[i] = first ? za.x : za.y;
-      if (has_b) rowb[i] = (i == 0) ? za.y : ((i & 1) ? zb.x : zb.y);
+    for (int t = tid; t < N / 2; t += NT) {
+      const cplx za0 = Z[PLAN::pos_out(t)], za1 = Z[PLAN::pos_out(t + 1)];
+      const cplx zb0 = Z[PLAN::pos_out((N - t) % N)], zb1 = Z[PLAN::pos_out(N - t - 1)];
+      qg_store16_wt(rowa + 2 * t, t == 0 ? za0.x : za0.y, za1.x);
+      if (has_b) qg_store16_wt(rowb + 2 * t, t == 0 ? za0.y : zb0.y, zb1.x);
     }
   } else {
     for (int i = tid; i < n; i += NT) {
@@ -558,32 +560,30 @@ __global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
 
   if (!INV) {
     // Xa_k = (Z_k + conj Z_{N-k})/2, Xb_k = (Z_k - conj Z_{N-k})/(2i)
+    // half-complex order r(1) = X_0, r(2k) = Re X_k, r(2k+1) = Im X_k, r(N) = X_{N/2}: the 16-byte aligned pair
+    // (2t, 2t+1) of the row is (Im X_t, Re X_{t+1}), (X_0, Re X_1) for t = 0 - one write-through store (qgcm_dev.h)
 #pragma unroll
-    for (int k = tid; k <= (PLAN::three_stage ? NC / 2 : H); k += NT) {
-      cplx z1 = Z[PLAN::pos_out(k)], z2 = Z[PLAN::pos_out((N - k) % N)];
-      double ar = 0.5 * (z1.x + z2.x), ai = 0.5 * (z1.y - z2.y);
-      double br = 0.5 * (z1.y + z2.y), bi = -0.5 * (z1.x - z2.x);
-      if (k == 0) {
-        rowa[0] = ar;
-        if (has_b) rowb[0] = br;
-      } else if (k == H) {
-        rowa[N - 1] = ar;
-        if (has_b) rowb[N - 1] = br;
-      } else {
-        rowa[2 * k - 1] = ar; rowa[2 * k] = ai;
-        if (has_b) { rowb[2 * k - 1] = br; rowb[2 * k] = bi; }
-      }
+    for (int t = tid; t < (PLAN::three_stage ? NC / 2 : H); t += NT) {
+      const cplx z1 = Z[PLAN::pos_out(t)], z2 = Z[PLAN::pos_out((N - t) % N)];
+      const cplx z3 = Z[PLAN::pos_out(t + 1)], z4 = Z[PLAN::pos_out(N - t - 1)];
+      const double ar = 0.5 * (z1.x + z2.x), ai = 0.5 * (z1.y - z2.y);
+      const double br = 0.5 * (z1.y + z2.y), bi = -0.5 * (z1.x - z2.x);
+      const double arn = 0.5 * (z3.x + z4.x), brn = 0.5 * (z3.y + z4.y);
+      qg_store16_wt(rowa + 2 * t, t == 0 ? ar : ai, arn);
+      if (has_b) qg_store16_wt(rowb + 2 * t, t == 0 ? br : bi, brn);
     }
   } else {
     double rsa = 0.0, rsb = 0.0;
 #pragma unroll
-    for (int j = tid; j < (PLAN::three_stage ? NC : N); j += NT) {
-      cplx z = Z[PLAN::pos_out(j)];
-      rowa[j] = z.x;
-      rsa += z.x;
+    for (int t = tid; t < (PLAN::three_stage ? NC : N) / 2; t += NT) { // 16-byte write-through stores (qgcm_dev.h)
+      const cplx z0 = Z[PLAN::pos_out(2 * t)], z1 = Z[PLAN::pos_out(2 * t + 1)];
+      qg_store16_wt(rowa + 2 * t, z0.x, z1.x);
+      rsa += z0.x;
+      rsa += z1.x;
       if (has_b) {
-        rowb[j] = -z.y;
-        rsb += -z.y;
+        qg_store16_wt(rowb + 2 * t, -z0.y, -z1.y);
+        rsb += -z0.y;
+        rsb += -z1.y;
       }
     }
     if (P.rowsum) {

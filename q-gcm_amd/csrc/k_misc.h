@@ -235,15 +235,18 @@ __device__ __forceinline__ void unpack_point(const QgUnpackParams &P, int gi, in
 template <int NL, bool BDY>
 __global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P, const QgBdyParams B) {
   const int nx = P.g.nx;
-  const int gi = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const int gi0 = blockIdx.x * blockDim.x + threadIdx.x + 1;
   const int gj = P.g.jlo + blockIdx.y; // owned local row
-  if (gi > nx || gj > P.g.jhi) return;
+  if (gj > P.g.jhi) return;
+  const bool valid = gi0 <= nx;
+  const int gi = valid ? gi0 : nx; // (lanes past the row keep the wave whole for the pair stores; they write nothing)
   const int G = gj + P.g.joff, nyg = P.g.nyg;
-  const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
+  const long o = (long)(gj - 1) * P.g.ldx + (gi0 - 1);
   double pl[NL];
   unpack_point<NL>(P, gi, gj, pl);
 #pragma unroll
-  for (int k = 0; k < NL; ++k) P.pnew[P.g.fstride * k + o] = pl[k];
+  for (int k = 0; k < NL; ++k) qg_pair_store_wt(P.pnew + P.g.fstride * k + o, pl[k], valid); // (qgcm_dev.h)
+  if (!valid) return;
   if (BDY) {
     const bool ns = (G == 1 || G == nyg);
     const bool we = (gi == 1 || gi == nx);

@@ -56,6 +56,18 @@ __device__ __forceinline__ void qg_store16_wt(double *p, double a, double b) {
 #endif
 }
 
+// Point-per-lane kernels: the even lane of every lane pair stores its own value and its right-hand neighbour's as one
+// 16-byte write-through store.  Every lane of the wave must arrive here (no divergent return before it); p = the
+// lane's own element, 16-byte aligned on even lanes; `valid`: the lane's element exists (an even lane whose neighbour
+// does not exist writes one element of row padding).
+__device__ __forceinline__ void qg_pair_store_wt(double *p, double v, bool valid) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xb1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xb1, 0xf, 0xf, true);
+  const double nb = __hiloint2double(hi, lo);
+  if (valid && !(threadIdx.x & 1)) qg_store16_wt(p, v, nb);
+}
+
 // scalars that live on the device between kernels (MODULE ochomog state)
 struct QgScalars {
   double dpioc[QG_MAXL], dpiocp[QG_MAXL], xon[QG_MAXL];
