@@ -130,6 +130,9 @@ int qgcm_hip_get_scalars(qgcm_hip_handle h, double *scal);
 /* diagnostics of the last ocinvq: xinhom(nlo); coef = hclco(nlo-1) [box] or
  * c1(nlo-1), c2(nlo-1), c3 [cyclic] */
 int qgcm_hip_get_inv_diag(qgcm_hip_handle h, double *xinhom, double *coef);
+/* Continuity monitors of the last ocinvq / atinvq of a zonally cyclic handle (MODULE monitor: ermaso, emfroc,
+ * src/ocisubs.F:268-283; ermasa, emfrat, src/atisubs.F:236-248): nlo-1 doubles each.  Synchronous. */
+int qgcm_hip_get_monitors(qgcm_hip_handle h, double *ermas, double *emfr);
 
 /* ---- the path ----------------------------------------------------------- */
 int qgcm_hip_qgostep(qgcm_hip_handle h);    /* replaces "call qgostep"        q-gcm.F:1243 */

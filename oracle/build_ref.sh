@@ -64,6 +64,11 @@ if [ "$CPL" = "1" ]; then
   for f in atconst athomog atstate; do $FCO $Q -c -I"$SRC" "$SRC/${f}_data.F"; done
   ATMOBJ="atconst_data.o athomog_data.o atstate_data.o atisubs.o qgasubs.o qgcm_ref_atmos.o"
 fi
+if [ "$CPL" != "1" ]; then
+  # ocean-only builds: MODULE atconst is USEd by xfosubs.F (below) in every configuration
+  $FCO $Q -c -I"$SRC" "$SRC/atconst_data.F"
+  ATMOBJ="atconst_data.o xfosubs.o"
+fi
 for f in occonst ochomog ocstate; do $FCO $Q -c -I"$SRC" "$SRC/${f}_data.F"; done
 $FCO -c -I"$SRC" "$SRC/monitor_data.F"
 $FCO -c -I"$SRC" "$SRC/intsubs.f"
@@ -80,6 +85,9 @@ $FCO -c -I"$SRC" "$SRC/radiate_data.F"
 $FCB $Q -c -I"$SRC" "$SRC/omlsubs.F"
 # validity scan
 $FCO $Q -c -I"$SRC" "$SRC/valsubs.F"
+# ocean-only builds: xforc's wekto / wekpo from the wind stress (src/xfosubs.F:566-683) - the
+# whole routine as it stands; in an ocean_only build everything before that section is compiled out
+if [ "$CPL" != "1" ]; then $FCO $Q -c -I"$SRC" "$SRC/xfosubs.F"; fi
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_harness.F90"
 $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_oml.F90"
 if [ "$CPL" = "1" ]; then $FC -O2 -fPIC -fopenmp -cpp $Q -c "$HERE/ref/qgcm_ref_atmos.F90"; fi

@@ -253,6 +253,52 @@ contains
 #endif
   end subroutine ref_get_scalars
 
+#ifdef ocean_only
+  ! Ekman pumping of an ocean-only run from the wind stress: `call xforc` as the main program does once at start-up
+  ! (src/q-gcm.F:820-826; src/xfosubs.F:566-683): wekto on the T grid, wekpo on the p grid.
+  subroutine ref_xforc(tx, ty, wekto_out, wekpo_out) bind(C, name='ref_xforc')
+    use intrfac, only : tauxo, tauyo
+    use ocstate, only : wekto, wekpo
+    use xfosubs, only : xforc
+    real(c_double), intent(in) :: tx(nxpo,nypo), ty(nxpo,nypo)
+    real(c_double), intent(out) :: wekto_out(nxto,nyto), wekpo_out(nxpo,nypo)
+    tauxo = tx
+    tauyo = ty
+    call xforc
+    wekto_out = wekto
+    wekpo_out = wekpo
+  end subroutine ref_xforc
+#endif
+
+  ! layer averages of the progress print-out / monitoring (pavgoc, qavgoc: src/monitor_diag.F:729-739 integrates po, qo
+  ! with boundary weights 1/2 by its PRIVATE genint - that file is the netCDF module and is not built here - and
+  ! multiplies by ocnorm = 1/(nxto*nyto), src/parameters_data.F:88).  The same trapezoid integral is the reference's
+  ! public xintp (src/intsubs.f:78-133), which constr uses on the same arrays.
+  subroutine ref_layer_avgs(pavg, qavg) bind(C, name='ref_layer_avgs')
+    use intsubs, only : xintp
+    real(c_double), intent(out) :: pavg(nlo), qavg(nlo)
+    double precision :: pint, qint
+    integer :: k
+    do k = 1, nlo
+      call xintp (pint, po(1,1,k), nxpo, nypo)
+      call xintp (qint, qo(1,1,k), nxpo, nypo)
+      pavg(k) = pint*ocnorm
+      qavg(k) = qint*ocnorm
+    enddo
+  end subroutine ref_layer_avgs
+
+  ! continuity monitors of the cyclic ocinvq (MODULE monitor, src/ocisubs.F:268-283); zeros in a box build
+  subroutine ref_get_monitors(erm, emf) bind(C, name='ref_get_monitors')
+    use monitor, only : ermaso, emfroc
+    real(c_double), intent(out) :: erm(nlo-1), emf(nlo-1)
+    erm = 0.0d0
+    emf = 0.0d0
+#ifdef cyclic_ocean
+    erm = ermaso
+    emf = emfroc
+#endif
+  end subroutine ref_get_monitors
+
   subroutine ref_set_scalars(scal) bind(C, name='ref_set_scalars')
     real(c_double), intent(in) :: scal(2*(nlo-1)+4*nlo)
     integer :: k, o

@@ -31,6 +31,9 @@ CONFIGS = {
     "cyc_small": (6, 10, "nxta", 4, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
     "box_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0),
     "cyc_socn5": (288, 108, "nxta", 36, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
+    # NAtl 1 km (BASELINE configs[4]): the grid lines of src/parameters_data.F.NAtl.1km:45,50 (40 km atmosphere,
+    # nxaooc = nyaooc = 120, ndxr = 40 -> 4801 x 4801 x 3 p-grid); used by tests/golden/make_golden_fullsize.py only
+    "box_natl1": (768, 192, 120, 120, 40, 3, "9.37456D-05", "1.75360D-11", 0),
     # coupled builds (no -Docean_only; -Dsb_hflux as examples/double_gyre_coupled/make.config.coupled): the ocean
     # path as above + the atmosphere path qgastep/atinvq/atqzbd.  Atmosphere (nxta+1, nyta+1, 3):
     # cpl_tiny 17x13 over the box_tiny ocean, cpl_small 33x21, cpl_natl5 = examples/double_gyre_coupled (385x97).
@@ -59,7 +62,12 @@ def build(cfg, force=False):
     if os.path.exists(lib_path(cfg)) and not force:
         return lib_path(cfg)
     p = CONFIGS[cfg]
-    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), cfg] + [str(x) for x in p])
+    env = dict(os.environ)
+    if cfg == "box_natl1":
+        # > 2 GB of static module arrays (po, pom, qo, qom alone are 4 x 553 MB): the medium code model keeps them in
+        # .lbss, out of the +-2 GB reach the small-model flang run-time objects need for their own data
+        env["FC"] = env.get("FC", "/opt/rocm/bin/amdflang") + " -mcmodel=medium"
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh"), cfg] + [str(x) for x in p], env=env)
     return lib_path(cfg)
 
 
@@ -220,6 +228,12 @@ class RefLib:
     def set_scalars(self, s):
         s = np.ascontiguousarray(s, dtype=np.float64)
         self.lib.ref_set_scalars(_dp(s))
+
+    def get_monitors(self):
+        """(ermaso, emfroc) of the last ocinvq (src/ocisubs.F:268-283; zeros in a box build)."""
+        e, f = np.zeros(self.nl - 1), np.zeros(self.nl - 1)
+        self.lib.ref_get_monitors(_dp(e), _dp(f))
+        return e, f
 
     def get_consts(self):
         nl = self.nl

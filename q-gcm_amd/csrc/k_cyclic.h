@@ -278,11 +278,20 @@ __device__ __forceinline__ void constr_cyc_partB(const QgCycConstrParams &P, int
     for (int m = 0; m < NL; ++m) pl = pl + P.ctm2l[m + NL * k] * aipmod[m];
     aiplay[k] = pl;
   }
-  // ocisubs.F:268-294 (the ermaso/emfroc monitors are diagnostics, not on this path)
+  // ocisubs.F:268-294 / atisubs.F:232-257: the continuity monitors ermaso, emfroc (ermasa, emfrat) - the new integral
+  // of the interface displacement against the one the entrainment predicts - then the step of dpioc / dpiocp
+  const double ecrit = 1.0e-13; // ocisubs.F:93, atisubs.F:86
+  const double area = ((double)P.g.nxt * P.dxo) * ((double)(P.g.nyg - 1) * P.dyo); // xlo*ylo (xla*yla)
 #pragma unroll
   for (int k = 0; k < NL - 1; ++k) {
+    const double est1 = P.g.atm ? aiplay[k] - aiplay[k + 1] /* dpiat, src/atisubs.F:256 */ : aiplay[k + 1] - aiplay[k];
+    const double est2 = sc->dpiocp[k] - P.tdto * P.gpoc[k] * sc->xon[k];
+    const double edif = est1 - est2;
+    const double esum = fabs(est1) + fabs(est2);
+    sc->ermas[k] = edif;
+    sc->emfr[k] = (esum > ecrit * area * P.tdto * P.gpoc[k]) ? 2.0 * edif / esum : 0.0;
     sc->dpiocp[k] = sc->dpioc[k];
-    sc->dpioc[k] = P.g.atm ? aiplay[k] - aiplay[k + 1] /* dpiat, src/atisubs.F:256 */ : aiplay[k + 1] - aiplay[k];
+    sc->dpioc[k] = est1;
   }
 }
 

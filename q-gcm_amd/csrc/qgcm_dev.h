@@ -72,6 +72,9 @@ __device__ __forceinline__ void qg_pair_store_wt(double *p, double v, bool valid
 struct QgScalars {
   double dpioc[QG_MAXL], dpiocp[QG_MAXL], xon[QG_MAXL];
   double xinhom[QG_MAXL], hclco[QG_MAXL];
+  // continuity monitors of the zonally cyclic ocinvq / atinvq (MODULE monitor: ermaso, emfroc / ermasa, emfrat;
+  // src/ocisubs.F:268-283, src/atisubs.F:236-248), per interface
+  double ermas[QG_MAXL], emfr[QG_MAXL];
   // cyclic
   double ocncs[QG_MAXL], ocncn[QG_MAXL], ocncsp[QG_MAXL], ocncnp[QG_MAXL];
   double enisoc[QG_MAXL], eninoc[QG_MAXL];

@@ -701,6 +701,19 @@ extern "C" int qgcm_hip_get_inv_diag(qgcm_hip_handle c, double *xinhom, double *
   return 0;
 }
 
+extern "C" int qgcm_hip_get_monitors(qgcm_hip_handle c, double *ermas, double *emfr) {
+  if (!c) QG_FAIL("qgcm_hip_get_monitors: null handle");
+  if (!c->g.cyc) QG_FAIL("qgcm_hip_get_monitors: the box ocean has no continuity monitors (src/ocisubs.F:268-283 is cyclic_ocean code)");
+  QgScalars h;
+  HIPCHECK(hipMemcpyAsync(&h, c->sc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < c->g.nl - 1; ++k) {
+    if (ermas) ermas[k] = h.ermas[k];
+    if (emfr) emfr[k] = h.emfr[k];
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // kernel launches
 // ---------------------------------------------------------------------------
@@ -2236,7 +2249,7 @@ extern "C" int qgcm_hip_comm_init(qgcm_hip_handle c, const char *id, int nbytes,
   m->rank = rank;
   m->nranks = nranks;
   const char *hp = getenv("QGCM_HIP_HALO_P2P");
-  m->halo_p2p = hp && atoi(hp) != 0;
+  m->halo_p2p = hp ? atoi(hp) != 0 : true; // default: the two neighbours only (an all-gather moves nranks x the bytes)
   m->th_len = slab_msg_len_oml(c);
   m->halo_len = halo_msg_len(c);
   c->sc_comm = m; // owned by the handle from here on (freed in qgcm_hip_destroy)

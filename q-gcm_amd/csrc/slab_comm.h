@@ -58,7 +58,7 @@ struct QgSlabComm {
   QgRccl *api = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
-  bool halo_p2p = false;
+  bool halo_p2p = true; // halo rows by grouped send/recv with the two neighbours (false: one all-gather of all edge rows)
   size_t th_len = 0, halo_len = 0;
   double *th_send = nullptr, *th_gath = nullptr; // slab summaries of the y sweeps (k_thomas.h, TH_MSG per mode and wavenumber)
   double *h_send = nullptr, *h_gath = nullptr;   // edge rows: [to lower | to upper] per rank

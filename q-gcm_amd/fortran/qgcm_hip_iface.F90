@@ -98,6 +98,11 @@ module qgcm_hip_iface
       type(c_ptr), value :: h
       real(c_double), intent(out) :: scal(*)
     end function
+    integer(c_int) function qgcm_hip_get_monitors(h, ermas, emfr) bind(C, name='qgcm_hip_get_monitors')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: ermas(*), emfr(*)
+    end function
     integer(c_int) function qgcm_hip_qgostep(h) bind(C, name='qgcm_hip_qgostep')
       import :: c_ptr, c_int
       type(c_ptr), value :: h

@@ -18,6 +18,9 @@
 !
 ! Build with the same cpp macros as the reference (-Docean_only ...).
 !-----------------------------------------------------------------------
+#ifdef sponge_layer_k247
+#error "qgcm_hip_shim: -Dsponge_layer_k247 (the sponge term of the leapfrog step, src/qgosubs.F:70-72,175-205) is not built on the device path: it is off in every BASELINE configuration; build without it"
+#endif
 module qgcm_hip_state
   use iso_c_binding
   use qgcm_hip_iface
@@ -151,8 +154,17 @@ contains
     ocncn = scal(2*(nlo-1)+nlo+1:2*(nlo-1)+2*nlo)
     ocncsp = scal(2*(nlo-1)+2*nlo+1:2*(nlo-1)+3*nlo)
     ocncnp = scal(2*(nlo-1)+3*nlo+1:2*(nlo-1)+4*nlo)
+    ! continuity monitors of ocinvq (src/ocisubs.F:268-283) for monnc_comp / monit.nc
+    call pull_monitors
 #endif
   end subroutine qgcm_hip_pull
+
+#ifdef cyclic_ocean
+  subroutine pull_monitors
+    use monitor, only : ermaso, emfroc
+    call qgcm_hip_check(qgcm_hip_get_monitors(qgcm_hip_handle, ermaso, emfroc), 'qgcm_hip_get_monitors')
+  end subroutine pull_monitors
+#endif
 
   subroutine qgcm_hip_shutdown
     if (c_associated(qgcm_hip_handle)) then
@@ -467,7 +479,13 @@ contains
     atmcnp = scal(2*(nla-1)+3*nla+1:2*(nla-1)+4*nla)
     call qgcm_hip_check(qgcm_hip_get_bsums(qgcm_hip_atm_handle, b), 'qgcm_hip_get_bsums (atmosphere)')
     ajisat = b(1:nla); ajinat = b(nla+1:2*nla); ap5sat = b(2*nla+1:3*nla); ap5nat = b(3*nla+1:4*nla)
+    call atm_pull_monitors   ! ermasa, emfrat of atinvq (src/atisubs.F:236-248)
   end subroutine qgcm_hip_atm_pull
+
+  subroutine atm_pull_monitors
+    use monitor, only : ermasa, emfrat
+    call qgcm_hip_check(qgcm_hip_get_monitors(qgcm_hip_atm_handle, ermasa, emfrat), 'qgcm_hip_get_monitors (atmosphere)')
+  end subroutine atm_pull_monitors
 
   subroutine qgcm_hip_atm_shutdown
     if (c_associated(qgcm_hip_atm_handle)) then

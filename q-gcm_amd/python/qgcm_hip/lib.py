@@ -45,7 +45,7 @@ SYMBOLS = [
     "qgcm_hip_create", "qgcm_hip_destroy", "qgcm_hip_last_error", "qgcm_hip_abi_version",
     "qgcm_hip_set_grid", "qgcm_hip_set_geometry", "qgcm_hip_set_homog_box", "qgcm_hip_set_homog_cyc",
     "qgcm_hip_set_state", "qgcm_hip_get_state", "qgcm_hip_set_forcing", "qgcm_hip_set_cyc_forcing",
-    "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag",
+    "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag", "qgcm_hip_get_monitors",
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_ocqbdy_host",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
     "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps",
@@ -90,6 +90,7 @@ def load_library():
     L.qgcm_hip_set_scalars.argtypes = [vp, dp]
     L.qgcm_hip_get_scalars.argtypes = [vp, dp]
     L.qgcm_hip_get_inv_diag.argtypes = [vp, dp, dp]
+    L.qgcm_hip_get_monitors.argtypes = [vp, dp, dp]
     for n in ("qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_sync"):
         getattr(L, n).argtypes = [vp]
     for n in ("qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd"):

@@ -169,6 +169,13 @@ class OceanModel:
         check(self.L.qgcm_hip_get_scalars(self.h, _dp(s)))
         return s
 
+    def get_monitors(self):
+        """(ermaso, emfroc) of the last ocinvq of a zonally cyclic ocean (src/ocisubs.F:268-283; atmosphere: ermasa,
+        emfrat): nlo-1 values each."""
+        e, f = np.zeros(self.cfg.nlo - 1), np.zeros(self.cfg.nlo - 1)
+        check(self.L.qgcm_hip_get_monitors(self.h, _dp(e), _dp(f)))
+        return e, f
+
     def get_inv_diag(self):
         nl = self.cfg.nlo
         x = np.zeros(nl)

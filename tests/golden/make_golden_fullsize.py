@@ -3,6 +3,9 @@
 true reference (oracle/_ref/libqgcm_ref_<cfg>.so) from the deterministic synthetic inputs of qgcm_hip.synth at
   natl5   961 x 961 x 3   examples/double_gyre_ocean_only  (BASELINE configs[1]; the bench workload's grid)
   socn5   4609 x 577 x 3  examples/southern_ocean_ocean_only (BASELINE configs[2])
+  natl1   4801 x 4801 x 3 src/parameters_data.F.NAtl.1km:45,50 + src/input.params.NAtl.1km with dta = 60 s, nstr = 3
+                          (BASELINE configs[4]; SURVEY 8d: as shipped, nstr = 1 never steps the ocean); steps 1 and 2,
+                          every 64th row / column; `python make_golden_fullsize.py natl1` (10 GB of host memory)
 stored as every 16th (socn5: 32nd) row / column of po, pom, qo, qom + the constraint scalars after steps 1 and 4
 (tests/golden/<cfg>_sample.npz, ~100 KB each).  The tests re-generate the inputs from the same synth code; a
 strided sample of the inputs is stored too and must match bit for bit.  Build container only."""
@@ -20,8 +23,9 @@ sys.path.insert(0, os.path.join(ROOT, "q-gcm_amd", "python"))
 import ref_binding  # noqa: E402
 from qgcm_hip import config, synth  # noqa: E402
 
-STRIDE = {"natl5": 16, "socn5": 32}
-REFCFG = {"natl5": "box_natl5", "socn5": "cyc_socn5"}
+STRIDE = {"natl5": 16, "socn5": 32, "natl1": 64}
+REFCFG = {"natl5": "box_natl5", "socn5": "cyc_socn5", "natl1": "box_natl1"}
+STEPS = {"natl1": (1, 2)}
 
 
 def make(name):
@@ -43,7 +47,7 @@ def make(name):
         r.set_cyc_forcing(txis, txin)
         out["in_txis"], out["in_txin"] = np.array(txis), np.array(txin)
     done = 0
-    for s in (1, 4):
+    for s in STEPS.get(name, (1, 4)):
         r.steps(done + 1, s - done)
         done = s
         for n, v in zip(("po", "pom", "qo", "qom"), r.get_state()):
@@ -57,6 +61,6 @@ def make(name):
 if __name__ == "__main__":
     if len(sys.argv) == 2:
         make(sys.argv[1])
-    else:  # one process per config: the reference libraries export identical symbols
-        for n in REFCFG:
+    else:  # one process per config: the reference libraries export identical symbols (natl1: on request only)
+        for n in ("natl5", "socn5"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), n])

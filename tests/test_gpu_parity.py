@@ -1,8 +1,11 @@
 """Parity tests proper: the HIP path (through the C ABI) against the golden
 vectors of the true reference and against the CPU oracle.  Needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
+from common import GOLDEN  # noqa: E402
 from common import (BOX_NAMES, CONFIG_NAMES, FIELDS, SNAPS, apply_inputs, load_golden, load_snapshot, make_oracle,
                     preset, relerr, scal_err, state_errs)
 
@@ -946,6 +949,95 @@ def test_full_size_natl1_slabs_vs_oracle():
         for sl in slabs:
             sl.close()
         o.close()
+
+
+def test_cyclic_continuity_monitors_vs_reference():
+    """ermaso / emfroc of the zonally cyclic ocinvq (MODULE monitor, src/ocisubs.F:268-283; round 2 skipped them): the
+    device values after each of six steps against the TRUE reference (tests/golden/cyc_tiny_monitors.npz,
+    make_golden_monitors.py) for a prescribed entrainment integral that makes them O(1e-4) relative numbers, in the
+    three stand-alone calls and inside qgcm_hip_steps."""
+    import importlib.util
+    from qgcm_hip import OceanModel
+    spec = importlib.util.spec_from_file_location("make_golden_monitors", os.path.join(GOLDEN, "make_golden_monitors.py"))
+    gm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gm)
+    g = load_golden("cyc_tiny_monitors")
+    cfg = preset("cyc_tiny")
+    po, wek, txis, txin = gm.inputs(cfg)
+    for fused in (False, True):
+        m = OceanModel(cfg)
+        try:
+            m.set_p(po, 0.98 * po)
+            m.set_forcing(wek, np.zeros_like(wek), np.array(gm.XON))
+            m.set_cyc_forcing(txis, txin, np.array(gm.ENIS), np.array(gm.ENIN))
+            for s in range(1, gm.NSTEPS + 1):
+                if fused:
+                    m.steps(1, s0=s)
+                else:
+                    m.qgostep()
+                    m.ocinvq()
+                    m.ocqbdy()
+                    if (s - 1) % 25 == 0:
+                        m.lf_average()
+                e, f = m.get_monitors()
+                sr = g["step%d_scal" % s]
+                scale = np.abs(sr[:cfg.nlo - 1]) + np.abs(sr[cfg.nlo - 1:2 * (cfg.nlo - 1)])  # |dpioc| + |dpiocp| ~ esum
+                assert (np.abs(e - g["step%d_ermaso" % s]) / scale).max() < 1e-12, (fused, s, e, g["step%d_ermaso" % s])
+                assert np.abs(f - g["step%d_emfroc" % s]).max() < 1e-11, (fused, s, f, g["step%d_emfroc" % s])
+                assert np.abs(g["step%d_emfroc" % s]).min() > 1e-5   # the fixture is not rounding noise
+        finally:
+            m.close()
+
+
+def test_full_size_natl1_eight_slabs_vs_reference_sample():
+    """BASELINE configs[4] in the decomposition the 8-GPU run uses: NAtl 1 km (4801 x 4801 x 3, dto = 180 s) cut into
+    EIGHT y-slabs of 600 / 601 rows (virtual ranks on this one GPU: the 8-GPU run only changes the transport), homogeneous
+    solutions by the distributed Helmholtz solve, two steps - against the REFERENCE ITSELF at this size:
+    tests/golden/natl1_sample.npz holds every 64th row and column of the true reference's state after steps 1 and 2
+    (built from src/parameters_data.F.NAtl.1km:45,50; tests/golden/make_golden_fullsize.py natl1)."""
+    import torch
+    from qgcm_hip import hostinit, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset("natl1")
+    nranks = 8
+    g = load_golden("natl1_sample")
+    st = int(g["stride"])
+    slabs = []
+    try:
+        consts = global_consts(cfg)
+        po = synth.gaussian_eddy(cfg, noise=1e-3)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        assert np.array_equal(po[::st, ::st], g["in_po"]) and np.array_equal(wek[::st, ::st], g["in_wekpo"])
+        zero2 = np.zeros((cfg.nxpo, cfg.nypo), order="F")
+        qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+        scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+        parts = partition(cfg.nypo, nranks)
+        assert sorted(set(g1 - g0 + 1 for g0, g1 in parts)) == [600, 601]
+        slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(parts)]
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.homsol()
+        so.scatter_state(po, po, qo, qo, wek, zero2, np.zeros(cfg.nlo - 1), scal)
+        del qo, zero2
+        for s in (1, 2):
+            so.steps(1, s0=s)
+            worst = {}
+            for g0, g1, fields in so.gather_local():
+                rows = np.arange(0, cfg.nypo, st)
+                rows = rows[(rows >= g0 - 1) & (rows <= g1 - 1)]     # sampled global rows (0-based) inside this slab
+                for f, x in zip(FIELDS, fields):
+                    ref = g["steps%d_%s" % (s, f)][:, rows // st, :]
+                    err = np.abs(x[::st, rows - (g0 - 1), :] - ref).max() / float(g["steps%d_%s_max" % (s, f)])
+                    worst[f] = max(worst.get(f, 0.0), float(err))
+            for f in FIELDS:
+                assert worst[f] < 1e-11, (s, worst)
+            sm, sr = slabs[0].get_scalars(), g["steps%d_scal" % s]
+            nl = cfg.nlo
+            scale = cfg.xlo * cfg.ylo * float(g["steps%d_po_max" % s])
+            assert np.abs(sm[:2 * (nl - 1)] - sr[:2 * (nl - 1)]).max() / scale < 1e-12
+    finally:
+        for sl in slabs:
+            sl.close()
 
 
 @pytest.mark.parametrize("name", ["cyc_med", "cyc_960"])

@@ -46,7 +46,8 @@ def test_atmosphere_init_from_p_on_the_device(name):
 @pytest.mark.parametrize("name", ["box_small", "cyc_small"])
 def test_wekpo_from_tau_on_the_device(name):
     """Ekman pumping from the stress on the device (src/xfosubs.F:566-645): the steps it drives are bitwise those
-    driven by the host-side restatement, which is pinned against the oracle's (tests/test_host_side.py)."""
+    driven by the host-side restatement - which is bitwise the REFERENCE's own `call xforc` on this very stress
+    (tests/golden/setup_ref.npz, tests/test_host_side.py::test_wekpo_from_tau_is_the_reference_xforc)."""
     from qgcm_hip import OceanModel
     cfg, g = preset(name), load_golden(name)
     tx, ty = synth.wind_stress(cfg)
@@ -75,9 +76,12 @@ def test_wekpo_from_tau_on_the_device(name):
 
 @pytest.mark.parametrize("name", ["box_small", "cyc_tiny"])
 def test_prsamp_numbers(name):
-    """The ocean numbers of prsamp (src/q-gcm.F:1933-2066): spot values bitwise, layer averages = xintp * ocnorm."""
+    """The ocean numbers of prsamp (src/q-gcm.F:1933-2066): spot values bitwise the device state, layer averages =
+    xintp * ocnorm - and both against the TRUE reference after the same 5 steps (tests/golden/setup_ref.npz:
+    the reference's xintp on its own po, qo; make_golden_setup.py)."""
     from qgcm_hip import OceanModel
     cfg, g = preset(name), load_golden(name)
+    gs = load_golden("setup_ref")
     m = OceanModel(cfg)
     try:
         m.set_p(g["in_po"], g["in_pom"])
@@ -92,5 +96,10 @@ def test_prsamp_numbers(name):
             assert abs(s["pavgoc"][k] - hostinit.xintp(po[:, :, k]) * ocnorm) < 1e-13 * np.abs(po).max()
             assert abs(s["qavgoc"][k] - hostinit.xintp(qo[:, :, k]) * ocnorm) < 1e-13 * np.abs(qo).max()
         assert s["sstmin"] == 1e30 and s["sstmax"] == -1e30   # no device mixed layer
+        pmx, qmx = float(gs[name + "_pomax"]), float(gs[name + "_qomax"])
+        assert np.abs(s["pavgoc"] - gs[name + "_pavg"]).max() < 1e-12 * pmx
+        assert np.abs(s["qavgoc"] - gs[name + "_qavg"]).max() < 1e-12 * qmx
+        assert np.abs(s["po_centre"] - gs[name + "_po_centre"]).max() < 1e-11 * pmx
+        assert np.abs(s["qo_centre"] - gs[name + "_qo_centre"]).max() < 1e-11 * qmx
     finally:
         m.close()

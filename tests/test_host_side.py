@@ -85,6 +85,24 @@ def test_wekpo_matches_oracle_restatement(case):
         assert abs(hostinit.xintp(wp) - wt.sum()) < 1e-12 * np.abs(wt).sum()
 
 
+@pytest.mark.parametrize("name", ["box_small", "cyc_small"])
+def test_wekpo_from_tau_is_the_reference_xforc(name):
+    """The ocean-only Ekman pumping of qgcm_hip.synth (the restatement the device kernels k_wekto / k_wekpo are held
+    to, bitwise, by tests/test_gpu_setup.py) against the REFERENCE's own `call xforc` on the same wind stress
+    (src/xfosubs.F:566-683, compiled into oracle/_ref by build_ref.sh; tests/golden/setup_ref.npz): bit for bit."""
+    import importlib.util
+    import os
+    from common import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_golden_setup", os.path.join(GOLDEN, "make_golden_setup.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    cfg, g = preset(name), load_golden("setup_ref")
+    tx, ty = mg.stress(cfg)
+    wekto, wekpo = synth.wekpo_from_tau(cfg, tx, ty)
+    assert np.array_equal(wekto, g[name + "_wekto"]) and np.array_equal(wekpo, g[name + "_wekpo"])
+    assert np.abs(wekpo).max() > 1e-7
+
+
 def test_xintp():
     rng = np.random.default_rng(5)
     v = np.asfortranarray(rng.standard_normal((23, 17)))
