@@ -348,6 +348,10 @@ int qgcm_hip_profile_steps(qgcm_hip_handle h, int s0, int n, double *ms, int *la
 /* device copy bandwidth probe (GB/s of read+write traffic) used as the
  * "measured peak" beside the nominal 8 TB/s. */
 int qgcm_hip_copy_bandwidth(qgcm_hip_handle h, size_t bytes, int reps, double *gbps);
+/* Rate (GB/s of read + written bytes) of a pure streaming kernel that reads nr fields and writes nw fields of
+ * field_bytes each, 16 bytes per lane: the practical ceiling for a kernel of that read : write mix on buffers of
+ * that size (15:6 = the tendency kernel, 3:3 = row transforms / Thomas sweep, 5:3 = fused inverse rows). */
+int qgcm_hip_stream_mix_bandwidth(qgcm_hip_handle h, int nr, int nw, size_t field_bytes, int reps, double *gbps);
 /* HIP stream of the handle as an opaque pointer (hipStream_t). */
 void *qgcm_hip_stream(qgcm_hip_handle h);
 

@@ -10,6 +10,7 @@ import json
 import sys
 
 NAMES = [("k_tend", "k_tend"), ("k_dst64_unpack", "k_dst_inv"), ("k_dst64<", "k_dst_fwd"), ("k_dst_box", "k_dst_fwd"),
+         ("k_rfft_cyc<true", "k_dst_inv"), ("k_rfft_cyc<false", "k_dst_fwd"),
          ("k_thomas", "k_thomas"), ("k_unpack", "k_unpack"), ("k_constr", "k_constr"), ("k_lf_average", "k_lf_average"),
          ("k_copy", "k_copy_1GiB_calibration")]
 

@@ -1,0 +1,62 @@
+"""Steps one workload on cuda:0 for rocprofv3 (profiles/collect.sh): `python3 profiles/tools/run_workload.py <what> [steps]`
+  socn5 / natl5 / <any ocean preset>   whole-domain handle, Gaussian-eddy IC + synthetic wind (+ k_copy calibration launches)
+  atmos                                385 x 97 x 3 atmospheric channel of double_gyre_coupled
+  natl1_slabs                          NAtl 1 km as eight y-slabs (virtual ranks on this one GPU)
+Eager launches (no graphs) so that every kernel shows in the trace with its own name."""
+import os
+import sys
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(ROOT, "q-gcm_amd", "python"))
+import numpy as np  # noqa: E402
+
+what = sys.argv[1]
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+if what == "atmos":
+    from qgcm_hip import AtmosModel, atmos_preset, synth
+    at = atmos_preset("cpl_natl5")
+    f = synth.atmos_fields(at)
+    a = AtmosModel(at, ddynat=f["ddynat"])
+    a.set_p(f["pa"], f["pam"])
+    a.set_forcing(f["wekpa"], f["entat"], f["xan"], f["txis"], f["txin"], f["enis"], f["enin"])
+    a.steps(200, s0=1)
+    ms = a.time_steps(1000, s0=201)
+    print("atmosphere 385x97x3: %.2f us per step (graph replay)" % (1e3 * ms / 1000))
+    for s in range(1201, 1201 + nsteps):   # eager, named kernels
+        a.qgastep(); a.atinvq(); a.atqzbd()
+    a.sync()
+elif what == "natl1_slabs":
+    import torch
+    from qgcm_hip import hostinit, preset, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg, P = preset("natl1"), 8
+    consts = global_consts(cfg)
+    po = synth.gaussian_eddy(cfg)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    z2 = np.zeros((cfg.nxpo, cfg.nypo), order="F")
+    qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+    scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+    slabs = [HipSlab(cfg, consts, g0, g1, r, P, sync_each_call=True) for r, (g0, g1) in enumerate(partition(cfg.nypo, P))]
+    so = SlabOcean(cfg, slabs, LocalComm(P, after=torch.cuda.synchronize))
+    so.homsol()
+    so.scatter_state(po, po, qo, qo, wek, z2, np.zeros(cfg.nlo - 1), scal)
+    so.steps(min(nsteps, 45), s0=1)
+    torch.cuda.synchronize()
+    print("finite", all(np.isfinite(f).all() for _, _, fs in so.gather_local() for f in fs))
+else:
+    from qgcm_hip import OceanModel, preset, synth
+    cfg = preset(what)
+    m = OceanModel(cfg)
+    po = synth.gaussian_eddy(cfg)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    m.set_p(po, po)
+    m.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+    if cfg.cyclic:
+        m.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
+    m.steps(100, s0=1)
+    ms = m.time_steps(400, s0=101)
+    print("%s: %.2f us per step (graph replay)" % (what, 1e3 * ms / 400))
+    m.profile_steps(nsteps, s0=501)   # eager launches with named kernels (brackets between them)
+    m.copy_bandwidth(1 << 30, 3)      # 1 GiB k_copy launches: the calibration of the FETCH_SIZE correction
+    print("finite", bool(np.isfinite(m.get_state()[0]).all()))

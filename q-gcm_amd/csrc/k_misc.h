@@ -375,6 +375,24 @@ __global__ __launch_bounds__(256) void k_halo_unpack(QgGeom g, double *po, doubl
 __global__ void k_noop() {}
 
 // device-to-device copy probe for the "measured peak" of the roofline
+// Measurement only (bench.py): a pure streaming kernel with a given read : write mix - NR fields read, NW fields
+// written, 16 bytes per lane, nothing else - on buffers of the workload's field size.  What the memory system gives
+// this kernel is the practical ceiling for a kernel of the same mix (profiles/tools/membw_mix.hip).
+template <int NR, int NW>
+__global__ __launch_bounds__(256) void k_stream_mix(const double2 *__restrict__ src, double2 *__restrict__ dst, long nper) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nper; i += stride) {
+    double2 v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = src[r * nper + i];
+    double2 acc = v[0];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) acc.x += v[r].x;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dst[w * nper + i] = double2{acc.x + w, acc.y};
+  }
+}
+
 __global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;

@@ -224,8 +224,11 @@ __device__ __forceinline__ void ts_march(const TsWave &Wv, const TsRules &R) {
   }
 }
 
+#ifndef TS_WAVES_PER_EU
+#define TS_WAVES_PER_EU 1
+#endif
 template <int NL, bool CYC>
-__global__ __launch_bounds__(TsCfg<NL>::NT) void k_tend_stream(const QgTendParams P, const QgCycSumParams S, const QgOmlFinal F) {
+__global__ __launch_bounds__(TsCfg<NL>::NT, TS_WAVES_PER_EU) void k_tend_stream(const QgTendParams P, const QgCycSumParams S, const QgOmlFinal F) {
   constexpr int SPW = TsCfg<NL>::SPW, NT = TsCfg<NL>::NT, SR = TS_S, PF = TS_PF;
   static_assert(NT >= TEND_NT && NT >= OML_NT, "the riders and the edge / line-sum workgroups use the first 256 threads");
   __shared__ double qlbuf[SPW][NL][SR][64]; // (q_new - beta*y [- ddyn]) of the unit's rows, per layer

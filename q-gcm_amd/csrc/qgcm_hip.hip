@@ -2576,6 +2576,48 @@ extern "C" int qgcm_hip_copy_bandwidth(qgcm_hip_handle c, size_t bytes, int reps
   return 0;
 }
 
+// Rate (GB/s of read + written bytes) of a pure streaming kernel that reads nr fields and writes nw fields of
+// field_bytes each (the mixes of the hot kernels: 15:6 tendency, 3:3 rows / sweep, 5:3 fused inverse rows).
+extern "C" int qgcm_hip_stream_mix_bandwidth(qgcm_hip_handle c, int nr, int nw, size_t field_bytes, int reps, double *gbps) {
+  if (!c || !gbps) QG_FAIL("qgcm_hip_stream_mix_bandwidth: null argument");
+  field_bytes = field_bytes / 4096 * 4096;
+  if (field_bytes == 0 || reps < 1) QG_FAIL("qgcm_hip_stream_mix_bandwidth: bad size / repetitions");
+  double2 *a = nullptr, *b = nullptr;
+  const long nper = (long)(field_bytes / sizeof(double2));
+  HIPCHECK(hipMalloc((void **)&a, field_bytes * nr));
+  HIPCHECK(hipMalloc((void **)&b, field_bytes * (nw > 0 ? nw : 1)));
+  HIPCHECK(hipMemsetAsync(a, 0, field_bytes * nr, c->stream));
+  HIPCHECK(hipMemsetAsync(b, 0, field_bytes * (nw > 0 ? nw : 1), c->stream));
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  auto launch = [&]() -> int {
+    const dim3 grid(2048), block(256);
+    if (nr == 15 && nw == 6) hipLaunchKernelGGL((k_stream_mix<15, 6>), grid, block, 0, c->stream, a, b, nper);
+    else if (nr == 3 && nw == 3) hipLaunchKernelGGL((k_stream_mix<3, 3>), grid, block, 0, c->stream, a, b, nper);
+    else if (nr == 5 && nw == 3) hipLaunchKernelGGL((k_stream_mix<5, 3>), grid, block, 0, c->stream, a, b, nper);
+    else return 1;
+    return 0;
+  };
+  int rc = 0;
+  for (int w = 0; w < 3 && !rc; ++w) rc = launch();
+  if (!rc) {
+    HIPCHECK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) launch();
+    HIPCHECK(hipEventRecord(e1, c->stream));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    *gbps = (double)field_bytes * (nr + nw) * reps / (ms * 1e-3) / 1e9;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(a);
+  hipFree(b);
+  if (rc) QG_FAIL("qgcm_hip_stream_mix_bandwidth: supported mixes are 15:6, 3:3 and 5:3");
+  return 0;
+}
+
 extern "C" void *qgcm_hip_stream(qgcm_hip_handle c) { return c ? (void *)c->stream : nullptr; }
 
 #ifdef QG_STAMPS

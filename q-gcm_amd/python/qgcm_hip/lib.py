@@ -58,7 +58,7 @@ SYMBOLS = [
     "qgcm_hip_oml_init", "qgcm_hip_oml_set_state", "qgcm_hip_oml_get_state", "qgcm_hip_oml_set_forcing",
     "qgcm_hip_oml", "qgcm_hip_oml_get_diag", "qgcm_hip_set_dtopoc", "qgcm_hip_valids",
     "qgcm_hip_init_from_p", "qgcm_hip_wekpo_from_tau", "qgcm_hip_prsamp",
-    "qgcm_hip_time_steps", "qgcm_hip_prepare_steps", "qgcm_hip_profile_steps", "qgcm_hip_copy_bandwidth", "qgcm_hip_stream",
+    "qgcm_hip_time_steps", "qgcm_hip_prepare_steps", "qgcm_hip_profile_steps", "qgcm_hip_copy_bandwidth", "qgcm_hip_stream_mix_bandwidth", "qgcm_hip_stream",
 ]
 
 _lib = None
@@ -140,6 +140,7 @@ def load_library():
     L.qgcm_hip_profile_steps.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_int),
                                          C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
     L.qgcm_hip_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, dp]
+    L.qgcm_hip_stream_mix_bandwidth.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, C.c_int, dp]
     L.qgcm_hip_stream.argtypes = [vp]
     L.qgcm_hip_stream.restype = vp
     _lib = L

@@ -296,6 +296,13 @@ class OceanModel:
         self.step_index = s0 + int(n)
         return {names[i].decode(): (ms[i], ln[i]) for i in range(nk.value)}
 
+    def stream_mix_bandwidth(self, nr, nw, field_bytes, reps=20):
+        """GB/s of a pure streaming kernel reading nr and writing nw fields of field_bytes (the practical ceiling for a
+        kernel of that mix at that size)."""
+        g = C.c_double()
+        check(self.L.qgcm_hip_stream_mix_bandwidth(self.h, int(nr), int(nw), C.c_size_t(int(field_bytes)), int(reps), C.byref(g)))
+        return g.value
+
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         g = C.c_double()
         check(self.L.qgcm_hip_copy_bandwidth(self.h, C.c_size_t(nbytes), int(reps), C.byref(g)))
