@@ -173,50 +173,61 @@ __device__ __forceinline__ void dst64_front(const QgDstParams &P, const double *
 #pragma unroll
     for (int k1 = 2; k1 < M; ++k1) tw1[k1] = cmul(tw1[k1 / 2], tw1[k1 - k1 / 2]);
   }
-  double snv[M];
-#pragma unroll
-  for (int n1 = 0; n1 < M; ++n1) {
-    const int j = 64 * n1 + lane;
-    snv[n1] = P.sintab[(j <= NS2) ? j : N - j];
-  }
   {
     double2 w = P.twid[M * lane];
     W64[lane] = {w.x, w.y};
   }
 
-  // ---- (1) pre-twiddle (dsint.f:19-33) into registers: a[n1] = z[64*n1 + lane].  The row elements come straight
-  // from global memory: z_j needs x(k), x(n+1-k) with k = min(j, N-j) - for the 64 lanes two contiguous 512-byte runs
-  // per row (one ascending, one descending).  Staging the rows in LDS first (round 1) cost 15 KB of LDS writes and
-  // 30 KB of LDS reads per row pair on the pipe that bounds this kernel.
+  // ---- (1) pre-twiddle (dsint.f:19-33) into registers: a[n1] = z[64*n1 + lane].  z_j and z_{N-j} are built from the
+  // SAME two row elements x(k), x(n+1-k), k = j <= N/2:  z_j = t1 + t2,  z_{N-j} = t2 - t1.  Round 2 let every lane
+  // load the pair of each of its M elements - every row element was requested twice, and a CU's rate of outstanding
+  // requests is what bounds the load phase of this one-generation kernel (phase stamps, DESIGN 3.6: rows in after
+  // 4.2 us against 3.0 us for the Thomas sweep's same bytes).  Now a lane loads the pairs of its elements of the LOWER
+  // half only (j <= N/2: registers n1 <= M/2), keeps z_j and hands z_{N-j} to its owner - lane (64 - lane) mod 64,
+  // register M-1-n1 (M-n1 for lane 0) - through the wave's LDS buffer, which is idle until the M-point DFTs are done:
+  // 32 instead of 60 row loads per wave, 8 LDS writes + 8 reads more.
+  constexpr int MH = M / 2; // registers n1 = 0..MH hold (some) elements of the lower half
   cplx a[M];
   {
     const double *rb = has_b ? rowb : rowa; // the odd last row has no partner: its loads are redirected and zeroed
     const double bsc = has_b ? 1.0 : 0.0;
-    double xav[M], xac[M], xbv[M], xbc[M];
+    double snv[MH + 1], xav[MH + 1], xac[MH + 1], xbv[MH + 1], xbc[MH + 1];
 #pragma unroll
-    for (int n1 = 0; n1 < M; ++n1) {
+    for (int n1 = 0; n1 <= MH; ++n1) {
       const int j = 64 * n1 + lane;
-      const int k = (j <= NS2) ? j : N - j;
+      const int k = (j <= NS2 + 1) ? j : 0;                    // (lanes past the middle of register MH: clamped, unused)
       const int i1 = k > 0 ? k - 1 : 0, i2 = k > 0 ? n - k : 0; // j = 0: z = 0, loads clamped
+      snv[n1] = P.sintab[(k <= NS2) ? k : 0];
       xav[n1] = rowa[i1];
       xac[n1] = rowa[i2];
       xbv[n1] = rb[i1];
       xbc[n1] = rb[i2];
     }
+    const int ml = (64 - lane) & 63; // owner of the mirrored elements
 #pragma unroll
-    for (int n1 = 0; n1 < M; ++n1) {
+    for (int n1 = 0; n1 <= MH; ++n1) {
       const int j = 64 * n1 + lane;
       const double va = xav[n1], ca = xac[n1], vb = bsc * xbv[n1], cb = bsc * xbc[n1];
       const double sn = snv[n1];
       const double t1a = va - ca, t2a = sn * (va + ca);
       const double t1b = vb - cb, t2b = sn * (vb + cb);
-      cplx z;
-      if (j <= NS2) z = {t1a + t2a, t1b + t2b};
-      else z = {t2a - t1a, t2b - t1b};
+      cplx z = {t1a + t2a, t1b + t2b};
       if (j == NS2 + 1) z = {4.0 * va, 4.0 * vb}; // k = N - j = j: both loads hit x(j)
       if (j == 0) z = {0.0, 0.0};
-      a[n1] = z;
+      a[n1] = z; // (register MH, lanes past the middle: overwritten from LDS below)
+      if (j >= 1 && j <= NS2) {
+        const int mn1 = (lane == 0) ? M - n1 : M - 1 - n1; // N - j = 64*mn1 + ml
+        F[mn1 * D64_ROW + ml + (ml >> 3)] = {t2a - t1a, t2b - t1b};
+      }
     }
+    wave_lds_sync();
+#pragma unroll
+    for (int n1 = MH; n1 < M; ++n1) {
+      const int j = 64 * n1 + lane;
+      const cplx zz = F[n1 * D64_ROW + lane + (lane >> 3)];
+      if (j >= NS2 + 2) a[n1] = zz;
+    }
+    wave_lds_sync(); // the buffer is rewritten below
   }
   dftM<M>(a);
 #pragma unroll

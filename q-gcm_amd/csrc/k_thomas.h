@@ -109,7 +109,7 @@ template <int R, int PHASE, bool CYCA = false, int KW = TH_KW>
 // (second launch bound = waves per SIMD.  The summary phase of a y-slab neither stores rows nor keeps them for the
 // backward sweep: with <= 10 rows per thread it fits 64 VGPRs, two workgroups share a CU and the launches of many
 // generations - NAtl 1 km: 900 workgroups - gain a quarter: 29 -> 21 us.  PHASE 2 at 64 VGPRs spills: 50 -> 70 us.)
-__global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8 : 1) void k_thomas(const QgThomasParams P) {
+__global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8 : ((KW == 8 && R <= 16) ? 4 : 1)) void k_thomas(const QgThomasParams P) {
   static_assert(TH_KW % KW == 0, "a workgroup's wavenumbers lie inside one block of the pivot tables");
   // pitch TH_KW + 1: the scans read / write these arrays transposed ([lane][wv]: 64 lanes at a stride of one row);
   // at a pitch of 16 doubles = 128 B every lane hit the same pair of banks (SQ_LDS_BANK_CONFLICT was 55 % of the
@@ -131,11 +131,19 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
     return;
   }
   QG_STAMP(1, 0);
+  // KW = 8 (half a 128-byte line per row): the two workgroups that share the lines of a 16-wavenumber block go to the
+  // SAME XCD - physical blocks b and b + 8 of every group of 16 (blocks are dealt round-robin over the 8 XCDs: the
+  // grid's x extent is a multiple of 8 then) - so that one L2 fetches each line once.
+  int bxl = (int)blockIdx.x;
+  if (KW == 8) {
+    const int nfull = ((int)gridDim.x - (CYCA ? 1 : 0)) / 16 * 16;
+    if (bxl < nfull) bxl = (bxl & ~15) + 2 * (bxl & 7) + ((bxl >> 3) & 1);
+  }
   const int kk = tid % KW;
   const int c = tid / KW;
   const int lane = tid & 63, wv = tid >> 6;
-  const int k = blockIdx.x * KW + kk;
-  const int kq = blockIdx.x * KW + wv; // wavenumber whose chunk maps this wave scans
+  const int k = bxl * KW + kk;
+  const int kq = bxl * KW + wv; // wavenumber whose chunk maps this wave scans
   const int m = blockIdx.y + P.layer0;
   const int nr = P.g.jr1 - P.g.jr0 + 1; // local rows jr0..jr1  <->  r = 0..nr-1
   const int ldw = P.g.ldw;
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
   const double ft = P.ftnorm;
 
   // 32-bit element offsets from a uniform base (one scalar pointer + one VGPR per address)
-  const double *wbase_c = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + blockIdx.x * KW;
+  const double *wbase_c = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + bxl * KW;
   double *wbase = const_cast<double *>(wbase_c);
   const unsigned off0 = (unsigned)(r0 * ldw + kk);
   // rows past the end of the slab: PHASE 0 (whole column, zero inflow at both ends) pads them with w = 0, b = 0 - the
@@ -164,13 +172,13 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
   // pivots of this chunk (src/ocisubs.F:472-477, tabulated by the host): rows below rcb from the block's table,
   // the stationary value after that
   {
-    const int tb = m * P.nblk + (blockIdx.x * KW) / TH_KW; // the tables are per block of TH_KW wavenumbers
+    const int tb = m * P.nblk + (bxl * KW) / TH_KW; // the tables are per block of TH_KW wavenumbers
     const int rcb = P.rcb[tb];
     const double binf = kok ? P.binf[(long)m * ldw + k] : 0.0;
 #pragma unroll
     for (int t = 0; t < R; ++t) b[t] = binf;
     if (r0 < rcb) {
-      const double *tab = P.ptab + (long)P.poff[tb] * TH_KW + (blockIdx.x * KW) % TH_KW + kk;
+      const double *tab = P.ptab + (long)P.poff[tb] * TH_KW + (bxl * KW) % TH_KW + kk;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         const int r = r0 + t;

@@ -987,6 +987,23 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
       default: hipLaunchKernelGGL((k_thomas<RV, 5, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;             \
     }                                                                                                                    \
   }
+  // 512-thread workgroups of 8 wavenumbers, two per CU (128 VGPRs), the pair that shares the 128-byte lines of a
+  // 16-wavenumber block on ONE XCD (k_thomas.h) - round 2 measured this shape slower, but with the pair's two halves
+  // of every line going through different L2s.  Measured with the pairing (r3): NAtl 5 km 10.6 -> 9.9 us (360
+  // workgroups spread over all 256 CUs instead of 180 on 180), SOcn 5 km 31.9 -> 30.8, NAtl 1 km slab sweep 50.0 ->
+  // 47.6.  QGCM_HIP_THOMAS_KW8=0 keeps the 1024-thread shape (A/B).
+  static const char *kw8env = getenv("QGCM_HIP_THOMAS_KW8");
+  const bool kw8 = kw8env ? kw8env[0] == '1' : true;
+  if (kw8 && (phase == 0 || phase == 2) && (c->thR == 8 || c->thR == 10 || c->thR == 12 || c->thR == 16)) {
+    switch (c->thR) {
+      case 8: QG_TH(8, 8); break;
+      case 10: QG_TH(10, 8); break;
+      case 12: QG_TH(12, 8); break;
+      default: QG_TH(16, 8); break;
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
   switch (c->thR) {
     case 1: QG_TH(1, 16); break;
     case 2: QG_TH(2, 16); break;
