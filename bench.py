@@ -442,7 +442,9 @@ def run_slabs(args, world, rank, local_rank, cfg5, real_stdout, barrier):
             try:
                 t_ag, ok_ag = timed(False)
                 t_pp, ok_pp = timed(True)
-                use_p2p = ok_pp and (t_pp < t_ag or not ok_ag)
+                # neighbour send/recv is the default transport (it moves 2 edge messages per rank, the all-gather
+                # nranks of them); the all-gather is taken only if it is measurably (> 2 %) faster on this node
+                use_p2p = ok_pp and (t_pp <= 1.02 * t_ag or not ok_ag)
                 slab.set_halo_p2p(use_p2p)
                 driver += "; halo rows by %s (all-gather %.1f us/step, send/recv %.1f us/step%s)" % (
                     "send/recv" if use_p2p else "all-gather", 1e4 * t_ag, 1e4 * t_pp, "" if ok_pp else ", send/recv NOT bitwise")
