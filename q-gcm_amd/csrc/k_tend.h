@@ -77,12 +77,17 @@ __host__ __device__ __forceinline__ TendTiling tend_tiling(const QgGeom &g) {
 // Point-wise part of the step for one p-point and all layers (qgosubs.F:173-219, ocisubs.F:117-139):
 // dq = dqdt of the point (0 outside the interior), d2bot = Del^2(pom) of the bottom layer,
 // qm / qo = old qom / qo of the point.
-template <int NL, bool CYC>
+// PAIR (the tile kernel's epilogue: EVERY lane of the wave calls, `valid` says whether its point exists): the new qo
+// and the work array leave as 16-byte write-through stores of two neighbouring columns (qgcm_dev.h: the 44 MB this
+// kernel writes no longer wait, dirty in L2, for the end-of-kernel flush); !PAIR: plain stores (edge workgroups).
+template <int NL, bool CYC, bool PAIR = false>
 __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj, const double *dq, double d2bot,
-                                           const double *qm, const double *qo, double wek, double ent, double ddy) {
+                                           const double *qm, const double *qo, double wek, double ent, double ddy,
+                                           bool valid = true) {
   const long fs = P.g.fstride;
   const long o = (long)(gj - 1) * P.g.ldx + (gi - 1);
-  if (gj + P.g.joff == 1 || gj + P.g.joff == P.g.nyg) {
+  const bool wallrow = (gj + P.g.joff == 1 || gj + P.g.joff == P.g.nyg);
+  if (!PAIR && wallrow) {
     // rows not stepped: the new-qo buffer keeps qo (qgosubs.F:214-219)
 #pragma unroll
     for (int k = 0; k < NL; ++k) P.qnew[fs * k + o] = qo[k];
@@ -106,19 +111,28 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
     double qn = qm[k] + P.tdto * qdot[k]; // qom + tdto*qdot
-    P.qnew[fs * k + o] = qn;
+    if (PAIR) {
+      // (rows not stepped keep qo, qgosubs.F:214-219; o is even on even lanes: the tile starts at an odd column)
+      qg_pair_store_wt(P.qnew + fs * k + o, wallrow ? qo[k] : qn, valid);
+    } else {
+      P.qnew[fs * k + o] = qn;
+    }
     ql[k] = qn - betay;
   }
   if (CYC && P.g.atm) ql[0] = ql[0] - ddy; // topography under layer 1, src/atisubs.F:117
   else ql[NL - 1] = ql[NL - 1] - ddy;
   int c = CYC ? gi - 1 : gi - 2;
-  if (c >= 0 && c < P.g.nk) {
+  const bool cok = c >= 0 && c < P.g.nk && !wallrow;
+  if (PAIR || cok) {
 #pragma unroll
     for (int m = 0; m < NL; ++m) {
       double qmm = 0.0;
 #pragma unroll
       for (int k = 0; k < NL; ++k) qmm = qmm + P.ctl2m[k + NL * m] * ql[k];
-      P.wrk[P.g.wstride * m + (long)(gj - 1) * P.g.ldw + c] = P.fnot * qmm;
+      // (plain stores: the box ocean's column c = gi - 2 is even on ODD lanes, and pairs that start on odd lanes leave
+      //  lanes 0 and 15 of every tile row with single elements - 8-byte plain stores into lines the 16-byte
+      //  write-through stores keep dropping from L2 took the kernel from 29.6 to 82 us)
+      if (valid && cok) P.wrk[P.g.wstride * m + (long)(gj - 1) * P.g.ldw + c] = P.fnot * qmm;
     }
   }
 }
@@ -161,7 +175,11 @@ __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTilin
   tend_point<NL, false>(P, gi, gj, dq, d2bot, qm, qo, wek, ent, ddy);
 }
 
-template <int NL, bool CYC>
+// WTQ: the epilogue stores the new qo in write-through pairs (tend_point<.., PAIR>) - worth 1 us per step while the
+// step's working set stays in the Infinity Cache (NAtl 5 km), but it costs 6 VGPRs (78: six waves per SIMD instead of
+// seven) and at HBM-bound sizes, where L2's own full-line evictions already spread the writes over the kernel, it made
+// the kernel slower (SOcn 5 km 95 -> 103 us, written through or not): the host picks the instantiation by size.
+template <int NL, bool CYC, bool WTQ>
 #ifndef TEND_WAVES_PER_EU
 #define TEND_WAVES_PER_EU 4
 #endif
@@ -386,20 +404,41 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   }
 
   // ---- forcing, bottom drag, leapfrog, projection ----------------------
+  if (WTQ) {
+    // (every lane goes through: the stores are pairs of neighbouring lanes; points outside the tile's part of the
+    //  domain compute on clamped operands and store nothing)
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    int ly = ty0 + r * (TEND_NT / TX);
-    int gi = i0 + tx, gj = j0 + ly;
-    if (gi > T.imax || gj > T.jmax) continue;
-    double dqp[NL], qmp[NL], qop[NL];
-    const bool wallrow = (gj + joff == 1 || gj + joff == nyg);
+    for (int r = 0; r < RPT; ++r) {
+      int ly = ty0 + r * (TEND_NT / TX);
+      const int gi0 = i0 + tx, gj0 = j0 + ly;
+      const bool valid = gi0 <= T.imax && gj0 <= T.jmax;
+      const int gi = valid ? gi0 : (gi0 <= T.imax ? gi0 : T.imax), gj = gj0 <= T.jmax ? gj0 : T.jmax;
+      double dqp[NL], qmp[NL], qop[NL];
+      const bool wallrow = (gj + joff == 1 || gj + joff == nyg);
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      dqp[k] = dq[k][r];
-      qmp[k] = e_qm[k][r];
-      qop[k] = wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+      for (int k = 0; k < NL; ++k) {
+        dqp[k] = dq[k][r];
+        qmp[k] = e_qm[k][r];
+        qop[k] = wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+      }
+      tend_point<NL, CYC, true>(P, gi0, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r], valid);
     }
-    tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      int ly = ty0 + r * (TEND_NT / TX);
+      int gi = i0 + tx, gj = j0 + ly;
+      if (gi > T.imax || gj > T.jmax) continue;
+      double dqp[NL], qmp[NL], qop[NL];
+      const bool wallrow = (gj + joff == 1 || gj + joff == nyg);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        dqp[k] = dq[k][r];
+        qmp[k] = e_qm[k][r];
+        qop[k] = wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+      }
+      tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
+    }
   }
   QG_STAMP(3, 7);
   QG_STAMP_DRAIN();

@@ -67,7 +67,6 @@ __device__ __forceinline__ void qg_pair_store_wt(double *p, double v, bool valid
   const double nb = __hiloint2double(hi, lo);
   if (valid && !(threadIdx.x & 1)) qg_store16_wt(p, v, nb);
 }
-
 // scalars that live on the device between kernels (MODULE ochomog state)
 struct QgScalars {
   double dpioc[QG_MAXL], dpiocp[QG_MAXL], xon[QG_MAXL];

@@ -843,9 +843,14 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   const int nextra = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : T.nedge);
   dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
-#define QG_TEND(NLV)                                                                              \
-  if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);    \
-  else hipLaunchKernelGGL((k_tend<NLV, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F)
+  // write-through pair stores of the new qo while the step's working set (~ 7 nl - 1 fields) stays in the 256 MiB
+  // Infinity Cache (NAtl 5 km: 150 MB: -1 us per step; SOcn 5 km's 425 MB: +8 us - k_tend.h)
+  const bool wtq = (double)g.fstride * 8.0 * (7 * g.nl - 1) < 200.0e6;
+#define QG_TEND(NLV)                                                                                       \
+  if (g.cyc && wtq) hipLaunchKernelGGL((k_tend<NLV, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);    \
+  else if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);     \
+  else if (wtq) hipLaunchKernelGGL((k_tend<NLV, false, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);       \
+  else hipLaunchKernelGGL((k_tend<NLV, false, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F)
   switch (g.nl) {
     case 2: QG_TEND(2); break;
     case 3: QG_TEND(3); break;
@@ -2523,7 +2528,14 @@ extern "C" int qgcm_hip_time_steps(qgcm_hip_handle c, int s0, int n, float *ms) 
   HIPCHECK(hipEventRecord(a, c->stream));
   if (qgcm_hip_steps(c, s0, n)) return 1;
   HIPCHECK(hipEventRecord(b, c->stream));
-  HIPCHECK(hipEventSynchronize(b));
+  // (polling, not hipEventSynchronize: a caller that times the call with its own clock should not pay the wake-up
+  //  latency of a blocking wait - tens of microseconds on a window of 20 steps)
+  for (;;) {
+    const hipError_t q = hipEventQuery(b);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) HIPCHECK(q);
+  }
+  (void)hipGetLastError(); // (hipErrorNotReady of the polls is not an error to report later)
   float t = 0.f;
   HIPCHECK(hipEventElapsedTime(&t, a, b));
   if (ms) *ms = t;
