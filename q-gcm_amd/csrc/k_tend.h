@@ -130,8 +130,8 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
 #pragma unroll
       for (int k = 0; k < NL; ++k) qmm = qmm + P.ctl2m[k + NL * m] * ql[k];
       // (plain stores: the box ocean's column c = gi - 2 is even on ODD lanes, and pairs that start on odd lanes leave
-      //  lanes 0 and 15 of every tile row with single elements - 8-byte plain stores into lines the 16-byte
-      //  write-through stores keep dropping from L2 took the kernel from 29.6 to 82 us)
+      //  lanes 0 and 15 of every tile row with single elements.  Measured: those as 8-byte plain stores into lines the
+      //  16-byte write-through stores keep dropping from L2: kernel 29.6 -> 82 us; as 8-byte sc1 stores: 33.3 us.)
       if (valid && cok) P.wrk[P.g.wstride * m + (long)(gj - 1) * P.g.ldw + c] = P.fnot * qmm;
     }
   }
