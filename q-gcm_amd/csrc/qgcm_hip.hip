@@ -24,10 +24,6 @@
 #include "k_misc.h"
 #include "k_cyclic.h"
 #include "k_rfft64.h"
-// one row per workgroup, complex FFT of half the row length (k_row1.h): (id, R1, R2, R3), R1*R2*R3 = nxto/2
-#define ROW1_NT 256
-#define QG_ROW1_PLANS(X) X(1, 12, 12, 16) X(2, 10, 15, 16)
-#include "k_row1.h"
 #include "k_oml.h"
 #include "k_valids.h"
 #include "k_setup.h"
@@ -93,9 +89,6 @@ struct qgcm_hip_ctx {
   bool dst_single = false; // generic row kernels run single-buffer (in-place) stages
   int fft3 = 0;            // long rows: three-stage register-radix plan of k_fft3.h (0 = none; index into QG_FFT3_PLANS)
   size_t fft3_lds = 0;
-  int ncu = 256;           // compute units of the device (persistent-workgroup launches)
-  int row1 = 0;            // ... or one row per workgroup at half the length (k_row1.h; index into QG_ROW1_PLANS)
-  size_t row1_lds = 0;
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
@@ -493,27 +486,6 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
     }
     QG_FFT3_PLANS(QG_FFT3_SETUP)
 #undef QG_FFT3_SETUP
-  }
-  // ... and the one-row-per-workgroup kernels of k_row1.h (QGCM_HIP_NO_ROW1=1: the row-pair kernels, for A/B + tests)
-  c->row1 = 0;
-  {
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) c->ncu = ncu;
-  }
-  if (getenv("QGCM_HIP_ROW1") && N % 2 == 0) { // opt-in: measured at parity with the row-pair kernels
-#define QG_ROW1_SETUP(ID, R1, R2, R3)                                                                                        \
-    if (N == 2 * R1 * R2 * R3) {                                                                                             \
-      typedef Fft3Plan<R1, R2, R3> PL;                                                                                       \
-      c->row1 = ID;                                                                                                          \
-      c->row1_lds = (size_t)PL::LDS_CPLX * sizeof(cplx);                                                                     \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft1_fwd<PL, ROW1_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->row1_lds)); \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft1_unpack_seq<PL, ROW1_NT, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->row1_lds)); \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft1_unpack_seq<PL, ROW1_NT, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->row1_lds)); \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft1_unpack<PL, ROW1_NT, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * c->row1_lds))); \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft1_unpack<PL, ROW1_NT, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * c->row1_lds))); \
-    }
-    QG_ROW1_PLANS(QG_ROW1_SETUP)
-#undef QG_ROW1_SETUP
   }
   c->grid_set = true;
   // slab summary constants (gain, backward image and column sums of the unit responses), once
@@ -929,16 +901,6 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
     grid.x += 1;
   }
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
-  if (c->row1 && g.cyc && !inverse && !c->force_generic_dst) {
-    // long cyclic rows, forward: one row per workgroup (k_row1.h)
-    dim3 grid1(nrows, nlayers);
-#define QG_ROW1_LAUNCH(ID, R1, R2, R3)                                                                                     \
-    if (c->row1 == ID) hipLaunchKernelGGL((k_rfft1_fwd<Fft3Plan<R1, R2, R3>, ROW1_NT>), grid1, dim3(ROW1_NT), c->row1_lds, st, P);
-    QG_ROW1_PLANS(QG_ROW1_LAUNCH)
-#undef QG_ROW1_LAUNCH
-    HIPCHECK(hipGetLastError());
-    return 0;
-  }
   if (c->fft3 && !c->force_generic_dst) {
     // long rows: three in-place register-radix stages (k_fft3.h)
 #define QG_FFT3_LAUNCH(ID, R1, R2, R3)                                                                                     \
@@ -1231,62 +1193,6 @@ static int launch_rfft_unpack(qgcm_hip_ctx *c, bool fuse_bdy, bool constr) {
   return 0;
 }
 
-// long cyclic rows inside qgcm_hip_steps: inverse rows + part B of the constraint algebra + homogeneous corrections +
-// modes -> layers + zonal-boundary PV in one launch, one row per workgroup (k_rfft1_unpack, k_row1.h)
-static bool can_fuse_rfft1_unpack(const qgcm_hip_ctx *c) {
-  return c->row1 && c->g.cyc && !c->g.atm && c->whole && !c->force_generic_dst && !c->no_fused_unpack && !c->no_fused_constr &&
-         c->d_cycq && c->g.nl >= 2 && c->g.nl <= 3 && c->g.ldx % 2 == 0 && c->g.fstride % 2 == 0;
-}
-
-static int launch_rfft1_unpack(qgcm_hip_ctx *c) {
-  const QgGeom &g = c->g;
-  QgDstParams D;
-  memset(&D, 0, sizeof(D));
-  D.g = g;
-  D.wrk = c->wrk;
-  D.twid = c->twid;
-  D.N = c->fftN;
-  D.nlayers = g.nl;
-  QgUnpackParams P;
-  memset(&P, 0, sizeof(P));
-  P.g = g;
-  P.wrk = c->wrk;
-  P.pnew = c->p[c->ip ^ 1];
-  P.sc = c->sc;
-  P.pch1 = c->pch1; P.pch2 = c->pch2; P.pbh = c->pbh;
-  for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
-  QgBdyParams B;
-  fill_bdy_params(c, B);
-  // persistent workgroups, one per CU (NL * 39-41 KB of LDS each), rows dealt round-robin
-  const int nrows1 = g.jr1 - g.jr0 + 1;
-  dim3 grid(nrows1 < c->ncu ? nrows1 : c->ncu);
-  KTimer t(c, KN_DSTI);
-  static const char *seqenv = getenv("QGCM_HIP_ROW1_SEQ");
-  const bool seq = seqenv && seqenv[0] == '1';
-#define QG_R1S(ID, R1, R2, R3)                                                                                              \
-  if (seq && c->row1 == ID) {                                                                                               \
-    typedef Fft3Plan<R1, R2, R3> PL;                                                                                        \
-    switch (g.nl) {                                                                                                         \
-      case 2: hipLaunchKernelGGL((k_rfft1_unpack_seq<PL, ROW1_NT, 2, true>), dim3(nrows1), dim3(ROW1_NT), c->row1_lds, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); break; \
-      default: hipLaunchKernelGGL((k_rfft1_unpack_seq<PL, ROW1_NT, 3, true>), dim3(nrows1), dim3(ROW1_NT), c->row1_lds, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); break; \
-    }                                                                                                                       \
-  }
-  QG_ROW1_PLANS(QG_R1S)
-#undef QG_R1S
-#define QG_R1U(ID, R1, R2, R3)                                                                                              \
-  if (!seq && c->row1 == ID) {                                                                                                      \
-    typedef Fft3Plan<R1, R2, R3> PL;                                                                                        \
-    switch (g.nl) {                                                                                                         \
-      case 2: hipLaunchKernelGGL((k_rfft1_unpack<PL, ROW1_NT, 2, true>), grid, dim3(2 * ROW1_NT), 2 * c->row1_lds, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); break; \
-      default: hipLaunchKernelGGL((k_rfft1_unpack<PL, ROW1_NT, 3, true>), grid, dim3(3 * ROW1_NT), 3 * c->row1_lds, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); break; \
-    }                                                                                                                       \
-  }
-  QG_ROW1_PLANS(QG_R1U)
-#undef QG_R1U
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-
 // box fast path: inverse row transform + modes -> layers (+ boundary PV) in one launch (k_dst64_unpack)
 static bool can_fuse_dst_unpack(const qgcm_hip_ctx *c) {
   return !c->g.cyc && !c->force_generic_dst && !c->no_fused_unpack && (c->fftN == 64 * 15 || c->fftN == 64 * 3) &&
@@ -1424,13 +1330,6 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
   // (the wave-per-row-pair kernels of k_rfft64.h have no such extra workgroup: they are fused with the unpack step
   //  above unless that is switched off, and then keep the stand-alone constraint launch)
   const bool generic_rows = c->force_generic_dst || !(c->fftN == 64 * 3 || c->fftN == 64 * 6 || c->fftN == 64 * 15);
-  if (in_step && fuse_bdy && generic_rows && can_fuse_rfft1_unpack(c)) {
-    // long cyclic rows (SOcn 5 km): part A rides in the Thomas launch, everything after the sweeps is ONE launch
-    if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, true)) return 1;
-    if (launch_rfft1_unpack(c)) return 1;
-    c->ip ^= 1;
-    return 0;
-  }
   if (c->g.cyc && in_step && !c->no_fused_constr && generic_rows) {
     // cyclic ocean with generic row sizes (SOcn 5 km), inside qgcm_hip_steps: part A of the constraint algebra rides in
     // the Thomas launch, part B in the inverse-row launch (it reads ksum and ybnd, not wrk): no launch of its own

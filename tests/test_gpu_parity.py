@@ -420,51 +420,6 @@ def test_long_row_transform_sizes(nxto, cyclic):
         o.close()
 
 
-@pytest.mark.parametrize("nxto,cyclic,nl", [(4608, True, 3), (4608, True, 2), (4800, False, 3)])
-def test_long_row_step_path(nxto, cyclic, nl, monkeypatch):
-    """The step path of the long-row kernels (k_row1.h: one row per workgroup, half-length complex FFT; the cyclic
-    inverse rows fused with part B of the constraint algebra, the homogeneous corrections, modes -> layers and the
-    zonal-boundary PV) on a 33-row basin: 6 steps against the CPU oracle, and against the row-pair kernels
-    (the default) at the rounding level of the two FFT algorithms."""
-    from qgcm_hip import OceanModel, synth
-    from qgcm_hip.config import OceanConfig
-    base = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True) if cyclic else dict(fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
-    nxa = nxto // 8
-    layers = dict(nlo=3) if nl == 3 else dict(nlo=2, hoc=(350.0, 3650.0), gpoc=(0.0262,), ah2oc=(0.0, 0.0), ah4oc=(2.0e9, 2.0e9))
-    try:
-        cfg = OceanConfig("longstep_%d" % nxto, nxa if cyclic else nxa + 2, 6, nxa, 4, 8, dxo=5.0e3, **layers, **base)
-    except TypeError:
-        if nl != 3:
-            pytest.skip("OceanConfig has no two-layer keyword set")
-        raise
-    assert cfg.nxto == nxto and cfg.nyto == 32 and cfg.nlo == nl
-    o = make_oracle(cfg)
-    monkeypatch.setenv("QGCM_HIP_ROW1", "1")
-    m = OceanModel(cfg)
-    monkeypatch.delenv("QGCM_HIP_ROW1")
-    m2 = OceanModel(cfg)
-    try:
-        po = synth.gaussian_eddy(cfg, noise=1e-2)
-        tx, ty = synth.wind_stress(cfg)
-        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
-        for mod in (m, m2, o):
-            mod.set_p(po, po)
-            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
-            if cyclic:
-                mod.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
-        m.steps(6, s0=1)
-        m2.steps(6, s0=1)
-        o.steps(1, 6)
-        for f, x, y, z in zip(FIELDS, m.get_state(), o.get_state(), m2.get_state()):
-            assert relerr(x, y) < TOL_CALL, f
-            assert relerr(x, z) < 1e-12, f
-        assert relerr(m.get_scalars(), m2.get_scalars()) < 1e-10
-    finally:
-        m.close()
-        m2.close()
-        o.close()
-
-
 @pytest.mark.parametrize("nyaooc,nranks", [(100, 1), (160, 1), (200, 2)])
 def test_long_columns(nyaooc, nranks):
     """Columns of 1025..2048 interior rows per handle keep 20 / 24 / 32 rows per thread in the tridiagonal kernel: those
