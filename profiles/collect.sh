@@ -1,10 +1,10 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root (gpurun -- 'bash profiles/collect.sh r3 [natl5|socn5|atmos|natl1_slabs]'):
+# Run ON THE GPU BOX from the repo root (gpurun -- 'bash profiles/collect.sh r3 [natl5|socn5|atmos|natl1_slabs|natl1_one_slab]'):
 #   natl5 (default): the default bench.py command
 #       pass 1  rocprofv3 --kernel-trace --stats        -> kernel durations
 #       pass 2  rocprofv3 --pmc FETCH_SIZE              (own pass, kernel-trace only)
 #       pass 3  rocprofv3 --pmc WRITE_SIZE              (own pass)
-#   socn5 / atmos / natl1_slabs: profiles/tools/run_workload.py <what> under the same passes (the HBM-bound
+#   socn5 / atmos / natl1_slabs / natl1_one_slab: profiles/tools/run_workload.py <what> under the same passes (the HBM-bound
 #       configuration BASELINE configs[2], the atmospheric channel, NAtl 1 km as eight slabs); PMC passes for socn5 only
 # then profiles/pmc_reduce.py turns the counter dumps into per-kernel HBM-side bytes per launch
 # (FETCH_SIZE x2 correction for gfx950, /opt/skills/guides/MI355X_MICROARCH.md).  Results land under

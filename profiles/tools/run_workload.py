@@ -1,7 +1,10 @@
 """Steps one workload on cuda:0 for rocprofv3 (profiles/collect.sh): `python3 profiles/tools/run_workload.py <what> [steps]`
   socn5 / natl5 / <any ocean preset>   whole-domain handle, Gaussian-eddy IC + synthetic wind (+ k_copy calibration launches)
   atmos                                385 x 97 x 3 atmospheric channel of double_gyre_coupled
-  natl1_slabs                          NAtl 1 km as eight y-slabs (virtual ranks on this one GPU)
+  natl1_slabs                          NAtl 1 km as eight y-slabs (virtual ranks on this one GPU, every kernel HBM-cold)
+  natl1_one_slab                       the same set-up, then ONE middle slab stepped alone: its fields stay in the
+                                       Infinity Cache between its kernels, as on its own GPU of eight (exchange buffers
+                                       held at the last real step's values; no collective is timed)
 Eager launches (no graphs) so that every kernel shows in the trace with its own name."""
 import os
 import sys
@@ -24,7 +27,7 @@ if what == "atmos":
     for s in range(1201, 1201 + nsteps):   # eager, named kernels
         a.qgastep(); a.atinvq(); a.atqzbd()
     a.sync()
-elif what == "natl1_slabs":
+elif what in ("natl1_slabs", "natl1_one_slab"):
     import torch
     from qgcm_hip import hostinit, preset, synth
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
@@ -40,7 +43,39 @@ elif what == "natl1_slabs":
     so = SlabOcean(cfg, slabs, LocalComm(P, after=torch.cuda.synchronize))
     so.homsol()
     so.scatter_state(po, po, qo, qo, wek, z2, np.zeros(cfg.nlo - 1), scal)
-    so.steps(min(nsteps, 45), s0=1)
+    if what == "natl1_slabs":
+        so.steps(min(nsteps, 45), s0=1)
+    else:
+        import time
+        so.steps(4, s0=1)          # real steps of all eight slabs: the exchange buffers hold consistent values
+        torch.cuda.synchronize()
+        r = P // 2
+        x = slabs[r]
+        x.sync_each_call = False
+
+        st = torch.cuda.ExternalStream(x.stream_ptr)
+        mine = so.th_gath[r][r * x.th_len:(r + 1) * x.th_len]
+        state0, scal0 = x.get_state(), x.get_scalars()
+
+        def one(n):
+            with torch.cuda.stream(st):
+                for _ in range(n):     # the stages of SlabOcean.step for this slab alone (s with (s - 1) % 25 != 0)
+                    x.stage(1, so.th_send[r])
+                    mine.copy_(so.th_send[r])   # its own summary is current, the other ranks' stay at the last real step
+                    x.stage(2, so.th_gath[r], so.h_to_lo[r], so.h_to_hi[r])
+                    x.stage(3, so.h_from_lo[r], so.h_from_hi[r], None, 0)
+            x.sync()
+        # A slab coupled to neighbours that stand still is not a stable system (it leaves the neighbourhood of the real
+        # solution after 5-6 steps): time 3 steps at a time, one untimed step after every restore of the state.
+        nch, per, tot = max(5, min(nsteps, 200) // 3), 3, 0.0
+        for _ in range(nch):
+            x.set_state(*state0); x.set_scalars(scal0)
+            one(1)
+            t0 = time.perf_counter()
+            one(per)
+            tot += time.perf_counter() - t0
+        print("NAtl 1 km, slab %d of %d (rows %d..%d) alone: %.1f us per step over %d x %d steps (wall clock, launches queued ahead); slab finite: %s"
+              % (r, P, x.g0, x.g1, 1e6 * tot / (nch * per), nch, per, all(np.isfinite(f).all() for f in x.get_state())))
     torch.cuda.synchronize()
     print("finite", all(np.isfinite(f).all() for _, _, fs in so.gather_local() for f in fs))
 else:
