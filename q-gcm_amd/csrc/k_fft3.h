@@ -136,7 +136,6 @@ __device__ __forceinline__ void fft3_powers(cplx w, cplx *tw) {
 template <int R1, int R2, int R3>
 struct Fft3Plan {
   static constexpr bool three_stage = true;
-  static constexpr int RA = R1, RB = R2, RC = R3;
   // rows of R3 are padded by one (stage 3: a thread owns a contiguous row), blocks of R2 rows by one more (the
   // post-processing reads X[k], k consecutive = consecutive k1 = consecutive blocks: without it every lane of a wave
   // hit the same LDS banks)

@@ -24,7 +24,6 @@
 #include "k_misc.h"
 #include "k_cyclic.h"
 #include "k_rfft64.h"
-#include "k_rfft3.h"
 #include "k_oml.h"
 #include "k_valids.h"
 #include "k_setup.h"
@@ -484,8 +483,6 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
       HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false, FFT3_NT, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
       HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false, PL, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
       HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true, PL, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft3_cyc<false, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
-      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft3_cyc<true, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
     }
     QG_FFT3_PLANS(QG_FFT3_SETUP)
 #undef QG_FFT3_SETUP
@@ -905,16 +902,11 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   }
   KTimer t(c, inverse ? KN_DSTI : KN_DSTF, st);
   if (c->fft3 && !c->force_generic_dst) {
-    // long rows: three in-place register-radix stages (k_fft3.h); cyclic rows with the packing / split steps folded
-    // into the first and last stage (k_rfft3.h; QGCM_HIP_RFFT3=0: the separate pre / post passes of k_rfft_cyc, A/B + tests)
-    static const char *r3env = getenv("QGCM_HIP_RFFT3");
-    const bool rfft3 = !(r3env && r3env[0] == '0');
+    // long rows: three in-place register-radix stages (k_fft3.h)
 #define QG_FFT3_LAUNCH(ID, R1, R2, R3)                                                                                     \
     if (c->fft3 == ID) {                                                                                                   \
       typedef Fft3Plan<R1, R2, R3> PL;                                                                                     \
       if (!g.cyc) hipLaunchKernelGGL((k_dst_box<false, FFT3_NT, PL>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);            \
-      else if (rfft3 && inverse) hipLaunchKernelGGL((k_rfft3_cyc<true, PL>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);     \
-      else if (rfft3) hipLaunchKernelGGL((k_rfft3_cyc<false, PL>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);               \
       else if (inverse) hipLaunchKernelGGL((k_rfft_cyc<true, PL, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);      \
       else hipLaunchKernelGGL((k_rfft_cyc<false, PL, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, st, P);                  \
     }
