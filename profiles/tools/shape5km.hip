@@ -74,6 +74,30 @@ __global__ __launch_bounds__(512) void k_cols(double *w, int nrows, int ldw, lon
     }
   }
 }
+// variant: 16 wavenumbers (a whole 128-byte line per row) per 512-thread workgroup, two wavenumbers = 16 bytes per lane
+__global__ __launch_bounds__(512) void k_cols16(double *w, int nrows, int ldw, long mstride, int delay) {
+  __shared__ double s[64][9];
+  const int kk = threadIdx.x & 7, c = threadIdx.x >> 3;
+  double *base = w + mstride * blockIdx.y + blockIdx.x * 16 + 2 * kk;
+  double2 v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int r = c * 16 + t;
+    v[t] = r < nrows ? *reinterpret_cast<const double2 *>(base + (long)r * ldw) : double2{0.0, 0.0};
+  }
+  wait_ticks(delay / 2);
+  s[c][kk] = v[0].x;
+  __syncthreads();
+  const double q = s[63 - c][kk];
+  wait_ticks(delay / 2);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int r = c * 16 + t;
+    const qg_v2d o = {v[t].x + q, v[t].y + q};
+    if (r < nrows) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(base + (long)r * ldw), "v"(o) : "memory");
+  }
+}
 int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int nrows = 959, ldw = 960, nl = 3;
@@ -100,6 +124,8 @@ int main() {
     timeit(nm, [&] { hipLaunchKernelGGL(k_cols<false>, dim3(ldw / 8, nl), dim3(512), 0, 0, w, nrows, ldw, mstride, delay); });
     snprintf(nm, 80, "columns (k_thomas shape, shipped) wait %.1f us", delay / 100.0);
     timeit(nm, [&] { hipLaunchKernelGGL(k_cols<true>, dim3(ldw / 8, nl), dim3(512), 0, 0, w, nrows, ldw, mstride, delay); });
+    snprintf(nm, 80, "columns (16 wavenumbers, 16-B lanes) wait %.1f us", delay / 100.0);
+    timeit(nm, [&] { hipLaunchKernelGGL(k_cols16, dim3(ldw / 16, nl), dim3(512), 0, 0, w, nrows, ldw, mstride, delay); });
   }
   return 0;
 }
