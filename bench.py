@@ -667,7 +667,8 @@ def main():
             "metric": "ocean timesteps/sec (NAtl 5km 3-layer qgostep+ocinvq+ocqbdy)",
             "value": round(steps_per_s, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            # (the basin is fixed as N grows - BASELINE.json's metric: the N > 1 lines say "strong" too)
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "double_gyre_ocean_only NAtl 5km, 961x961x3 p-grid, dto=540s, "
                                    "Gaussian-eddy IC + double-gyre wind, oml off",
@@ -675,6 +676,9 @@ def main():
                        "parallelism": "single GPU"},
             "model_years_per_day": round(cfg.model_years_per_day(steps_per_s), 1),
             "hip_event_ms_per_step": round(ev_ms / args.steps, 5),
+            # steps run before the timed window opens: --warmup + the untimed rehearsal of the timed call (graph
+            # capture / instantiation and the GPU's clock ramp stay outside the window, see above)
+            "untimed_steps_before_window": args.warmup + done,
             "launch_mode": "HIP graphs: %d x 50-step block(s) + %s, %d eager step(s); built and replayed once before the window" % (
                 args.steps // 50, ("one %d-step block" % ((args.steps % 50) & ~1)) if (args.steps % 50) >= 2 else "no tail block",
                 (args.steps % 50) % 2),
@@ -682,6 +686,8 @@ def main():
             "step_hbm_frac": round(56 * npts * 8.0 * (args.steps / (ev_ms * 1e-3)) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom),
+                         "traffic_source": "committed rocprofv3 --pmc collection of this command (profiles/pmc_traffic.json, "
+                                           "profiles/collect.sh), not measured in this run",
                          "avg_launch_us": round(avg_us, 3), "algorithmic_bytes_per_launch": abytes,
                          "reference_algorithm_bytes_per_launch": f_survey * npts * 8.0,
                          "frac_reference_algorithm_bytes": round(f_survey * npts * 8.0 / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -757,7 +763,9 @@ def main():
                                          "algorithmic_bytes_per_launch": nb_s,
                                          "measured_stream_same_mix_GBps": round(stream_s, 1),
                                          "frac_of_measured_stream": round(ach_s / stream_s, 4),
-                                         "traffic": pmc_traffic("k_tend", "pmc_traffic_socn5.json")}
+                                         "traffic": pmc_traffic("k_tend", "pmc_traffic_socn5.json"),
+                                         "traffic_source": "committed rocprofv3 --pmc collection (profiles/pmc_traffic_socn5.json), "
+                                                           "not measured in this run"}
         except Exception as e:  # noqa: BLE001 - secondary figure only
             out["socn5_cyclic"] = {"error": repr(e)}
         # Secondary figure: BASELINE configs[3] double_gyre_coupled - the NAtl 5 km ocean under the 385 x 97 x 3

@@ -39,7 +39,10 @@ extern "C" {
 #endif
 
 #define QGCM_HIP_MAXL 8 /* max number of QG layers supported (nlo <= 8) */
-#define QGCM_HIP_ABI_VERSION 2 /* 2: qgcm_hip_params.atmos + the atmosphere entry points */
+/* 2: qgcm_hip_params.atmos + the atmosphere entry points
+ * 3: qgcm_hip_get_monitors (required by the Fortran shim), qgcm_hip_prepare_steps, qgcm_hip_stream_mix_bandwidth,
+ *    qgcm_hip_set_sponge; halo rows of qgcm_hip_slab_steps default to neighbour send/recv */
+#define QGCM_HIP_ABI_VERSION 3
 
 typedef struct qgcm_hip_ctx *qgcm_hip_handle;
 
@@ -117,6 +120,12 @@ int qgcm_hip_get_state(qgcm_hip_handle h, double *po, double *pom, double *qo, d
 /* wekpo(nxpo,nypo), entoc(nxpo,nypo), xon(nlo-1)  (written by xforc / oml) */
 int qgcm_hip_set_forcing(qgcm_hip_handle h, const double *wekpo, const double *entoc,
                          const double *xon);
+/* The fork's sponge layer (cpp option sponge_layer_k247): the leapfrog step of qgostep gains
+ *   + tdto*c1_spl*r_spl(i,j)*(qom(i,j,k) - beta*yporel(j))            src/qgosubs.F:203-205
+ * r_spl(nxpo,nypo): the ramp of MODULE occonst (src/occonst_data.F:100-105) as the main program sets it
+ * (src/q-gcm.F:1154-1168; a y-slab handle takes its local rows); c1_spl: src/parameters_data.F:144.
+ * NULL switches the term off again (the default: no BASELINE configuration defines the option). */
+int qgcm_hip_set_sponge(qgcm_hip_handle h, const double *r_spl, double c1_spl);
 /* cyclic only: txisoc, txinoc (xforc), enisoc/eninoc(nlo-1) (oml) */
 int qgcm_hip_set_cyc_forcing(qgcm_hip_handle h, double txisoc, double txinoc,
                              const double *enisoc, const double *eninoc);
@@ -220,6 +229,11 @@ int qgcm_hip_halo_unpack(qgcm_hip_handle h, const double *from_lower_dev, const 
  * thomas_phase 2 / a whole-domain sweep; nlo doubles, synchronous).  No host-side solver is involved. */
 int qgcm_hip_wrk_fill(qgcm_hip_handle h, double value);
 int qgcm_hip_wrk_get(qgcm_hip_handle h, double *wrk);
+/* rows of a (nxpo, nyl, nlo) host block into the work array (the counterpart of qgcm_hip_wrk_get; walls ignored):
+ * with qgcm_hip_row_transform this exposes the row transforms that replace FFTPACK's dsint / drfftf / drfftb
+ * (src/ocisubs.F:461-463, 494-499, 566-568, 601-605) by themselves - forward: dsint resp. drfftf, unnormalised, the
+ * cyclic spectrum in FFTPACK's half-complex order; inverse: dsint resp. drfftb.  Synchronous. */
+int qgcm_hip_wrk_set(qgcm_hip_handle h, const double *wrk);
 int qgcm_hip_area_integrals(qgcm_hip_handle h, double *xin);
 
 /* One call per communication-free stage of a distributed step (fewer host round trips):

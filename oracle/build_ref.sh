@@ -49,6 +49,11 @@ sed -e "s|^      PARAMETER ( nxta = .*|      PARAMETER ( nxta = $NXTA, nyta = $N
     -e "s|^      PARAMETER ( nxaooc = .*|      PARAMETER ( nxaooc = $NXAOOC, nyaooc = $NYAOOC, ndxr = $NDXR, nlo = $NLO )|" \
     -e "s|^      PARAMETER ( fnot = .*|      PARAMETER ( fnot = $FNOT, beta = $BETA )|" \
     "$REF/examples/double_gyre_ocean_only/parameters_data.F.dg_oo" > parameters_data.F
+# -Dsponge_layer_k247 builds: the example dimension files lack the fork's sponge constants ("fork
+# breakage"); the two lines of src/parameters_data.F:140,144 are appended, as q-gcm_amd/fortran/dropin/build_dropin.sh does
+case "$EXTRA" in *sponge_layer_k247*)
+  sed -i -e "s|^      END MODULE parameters|      double precision :: c1_spl, l_spl\n      PARAMETER ( c1_spl = -2.5D-5, l_spl = 4.0D5 )\n      END MODULE parameters|" parameters_data.F ;;
+esac
 
 Q="-Docean_only"
 if [ "$CPL" = "1" ]; then Q=""; fi
@@ -98,4 +103,6 @@ $FC -shared -fopenmp -o "$OUT/libqgcm_ref_$CFG.so" \
     intrfac_data.o radiate_data.o omlsubs.o valsubs.o qgcm_ref_harness.o qgcm_ref_oml.o $ATMOBJ \
     -L"$MKLDIR" -Wl,--no-as-needed -lmkl_gf_lp64 -lmkl_sequential -lmkl_core -Wl,--as-needed -Wl,-rpath,"$MKLDIR" -Wl,-rpath,/opt/rocm/lib/llvm/lib
 
+# the per-config dimension file is edited text of a reference source: it does not stay in a directory that travels
+rm -f parameters_data.F
 echo "built $OUT/libqgcm_ref_$CFG.so"

@@ -45,6 +45,7 @@ def lib():
         L.qgo_get_state.argtypes = [C.c_void_p, dp, dp, dp, dp]
         L.qgo_set_forcing.argtypes = [C.c_void_p, dp, dp, dp]
         L.qgo_set_cyc_forcing.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, dp]
+        L.qgo_set_sponge.argtypes = [C.c_void_p, dp, C.c_double]
         L.qgo_get_scalars.argtypes = [C.c_void_p, dp]
         L.qgo_set_scalars.argtypes = [C.c_void_p, dp]
         L.qgo_get_inv_diag.argtypes = [C.c_void_p, dp, dp]
@@ -180,6 +181,13 @@ class Oracle:
         es = np.zeros(self.nl - 1) if enis is None else np.ascontiguousarray(enis, dtype=np.float64)
         en = np.zeros(self.nl - 1) if enin is None else np.ascontiguousarray(enin, dtype=np.float64)
         self.L.qgo_set_cyc_forcing(self.h, txis, txin, _dp(es), _dp(en))
+
+    def set_sponge(self, r_spl, c1_spl):
+        if r_spl is None:
+            self.L.qgo_set_sponge(self.h, None, 0.0)
+            return
+        r = np.asfortranarray(r_spl, dtype=np.float64)
+        self.L.qgo_set_sponge(self.h, _dp(r), float(c1_spl))
 
     def get_scalars(self):
         s = np.zeros(self.nscal)

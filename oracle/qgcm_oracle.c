@@ -29,6 +29,8 @@ struct qgo_ctx {
   int atmos;
   double fnot, beta, dxo, dyo, dxom2, dto, tdto, delek, bccooc, xlo, ylo;
   double *ah2oc, *ah4oc, *hoc, *gpoc, *yporel, *ddynoc;
+  double *r_spl; /* sponge-layer ramp (cpp option sponge_layer_k247, src/occonst_data.F:100-105) or NULL */
+  double c1_spl; /* src/parameters_data.F:144 */
   double *amatoc, *ctl2moc, *ctm2loc, *rdm2oc; /* (nl,nl) Fortran order */
   double aoc, *bd2oc;
   /* state */
@@ -762,7 +764,7 @@ qgo_ctx *qgo_create_atmos(int nxpa, int nypa, int nla, double fnot, double beta,
 
 void qgo_destroy(qgo_ctx *c) {
   if (!c) return;
-  double *ptrs[] = {c->ah2oc, c->ah4oc, c->hoc, c->gpoc, c->yporel, c->ddynoc, c->amatoc, c->ctl2moc,
+  double *ptrs[] = {c->ah2oc, c->ah4oc, c->hoc, c->gpoc, c->yporel, c->ddynoc, c->r_spl, c->amatoc, c->ctl2moc,
                     c->ctm2loc, c->rdm2oc, c->bd2oc, c->po, c->pom, c->qo, c->qom, c->wekpo, c->entoc,
                     c->xon, c->dpioc, c->dpiocp, c->ochom, c->aipohs, c->cdiffo, c->cdhoc, c->cdhlu,
                     c->pch1oc, c->pch2oc, c->pbhoc, c->aipcho, c->hc1soc, c->hc2soc, c->hc1noc, c->hc2noc,
@@ -993,6 +995,19 @@ void qgo_set_forcing(qgo_ctx *c, const double *wekpo, const double *entoc, const
   if (wekpo) memcpy(c->wekpo, wekpo, sizeof(double) * N);
   if (entoc) memcpy(c->entoc, entoc, sizeof(double) * N);
   if (xon) memcpy(c->xon, xon, sizeof(double) * (c->nl - 1));
+}
+
+/* cpp option sponge_layer_k247: ramp r_spl(nxpo,nypo) as the main program sets it (src/q-gcm.F:1154-1168) and c1_spl
+   (src/parameters_data.F:144); NULL switches the term off */
+void qgo_set_sponge(qgo_ctx *c, const double *r_spl, double c1_spl) {
+  free(c->r_spl);
+  c->r_spl = NULL;
+  c->c1_spl = 0.0;
+  if (!r_spl) return;
+  size_t N = (size_t)c->nx * c->ny;
+  c->r_spl = dalloc(N);
+  memcpy(c->r_spl, r_spl, sizeof(double) * N);
+  c->c1_spl = c1_spl;
 }
 
 void qgo_set_cyc_forcing(qgo_ctx *c, double txis, double txin, const double *enis, const double *enin) {
@@ -1239,6 +1254,10 @@ void qgo_qgostep(qgo_ctx *c) {
       for (int k = 1; k <= nl; ++k) {
         double qold = c->qo[IX3(i, j, k)];
         c->qo[IX3(i, j, k)] = c->qom[IX3(i, j, k)] + tdto * qdot[k - 1];
+        /* sponge layer of the k247 fork, src/qgosubs.F:203-205 (betay = beta*yporel(j), :177) */
+        if (c->r_spl)
+          c->qo[IX3(i, j, k)] = c->qo[IX3(i, j, k)] +
+                                tdto * c->c1_spl * c->r_spl[IX(i, j)] * (c->qom[IX3(i, j, k)] - c->beta * c->yporel[j - 1]);
         c->qom[IX3(i, j, k)] = qold;
       }
     }

@@ -52,6 +52,7 @@ void qgo_set_state(qgo_ctx *c, const double *po, const double *pom, const double
 void qgo_get_state(qgo_ctx *c, double *po, double *pom, double *qo, double *qom);
 void qgo_set_forcing(qgo_ctx *c, const double *wekpo, const double *entoc, const double *xon);
 void qgo_set_cyc_forcing(qgo_ctx *c, double txis, double txin, const double *enis, const double *enin);
+void qgo_set_sponge(qgo_ctx *c, const double *r_spl, double c1_spl); /* src/qgosubs.F:203-205; NULL = off */
 /* scal = dpioc(nlo-1), dpiocp(nlo-1), ocncs, ocncn, ocncsp, ocncnp (nlo each; zero for box) */
 void qgo_get_scalars(qgo_ctx *c, double *scal);
 void qgo_set_scalars(qgo_ctx *c, const double *scal);

@@ -241,6 +241,14 @@ contains
     enddo
   end subroutine ref_atm_get_bsums
 
+  ! continuity monitors of the last atinvq (MODULE monitor: ermasa, emfrat; src/atisubs.F:236-248)
+  subroutine ref_atm_get_monitors(erm, emf) bind(C, name='ref_atm_get_monitors')
+    use monitor, only : ermasa, emfrat
+    real(c_double), intent(out) :: erm(nla-1), emf(nla-1)
+    erm = ermasa
+    emf = emfrat
+  end subroutine ref_atm_get_monitors
+
   subroutine ref_atm_get_consts(amat, cl2m, cm2l, rdm2, bd2, ypr, aat_out) bind(C, name='ref_atm_get_consts')
     real(c_double), intent(out) :: amat(nla,nla), cl2m(nla,nla), cm2l(nla,nla), &
                                    rdm2(nla), bd2(nxta), ypr(nypa), aat_out

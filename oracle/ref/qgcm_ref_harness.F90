@@ -18,6 +18,7 @@
 !   tridiagonal coefficients   src/q-gcm.F:932-954
 !   homsol / constr / qcomp    src/q-gcm.F:976, 711, 719-731
 !   time loop + LF averaging   src/q-gcm.F:1243-1249, 1328-1366
+!   sponge-layer ramp r_spl    src/q-gcm.F:1154-1168   (builds with -Dsponge_layer_k247 only)
 !-----------------------------------------------------------------------
 module qgcm_ref_harness
   use iso_c_binding
@@ -169,12 +170,43 @@ contains
     call dsinti (nxto-1, oftwrk)
 #endif
 
+#ifdef sponge_layer_k247
+    ! src/q-gcm.F:1154-1168 (option nospl_in_ewbdy_k247 not defined): a Gaussian ramp in the distance to the
+    ! nearer zonal boundary plus one in the distance to the nearer meridional boundary
+    do j = 1, nypo
+      do i = 1, nxpo
+        r_spl(i,j) = 0.0d0 &
+                   + exp( -2.0d0 * PI_ * ( ( 0.5d0 * dyo * dble(nypo) &
+                     - abs( dyo * dble(j) - 0.5d0 * dyo * dble(nypo) ) ) / ( l_spl ) )**2.0d0 ) &
+                   + exp( -2.0d0 * PI_ * ( ( 0.5d0 * dxo * dble(nxpo) &
+                     - abs( dxo * dble(i) - 0.5d0 * dxo * dble(nxpo) ) ) / ( l_spl ) )**2.0d0 )
+      enddo
+    enddo
+#endif
+
     ! src/q-gcm.F:976.  In a coupled build homsol also does the atmosphere, whose constants
     ! ref_atm_init sets: there the caller runs ref_homsol after both initialisations.
 #ifdef ocean_only
     call homsol
 #endif
   end subroutine ref_init
+
+  ! the sponge-layer ramp and constants of a -Dsponge_layer_k247 build (on = 0 and zeros otherwise)
+  subroutine ref_get_sponge(on, rspl_out, c1, lspl) bind(C, name='ref_get_sponge')
+    integer(c_int), intent(out) :: on
+    real(c_double), intent(out) :: rspl_out(nxpo,nypo), c1, lspl
+#ifdef sponge_layer_k247
+    on = 1
+    rspl_out = r_spl
+    c1 = c1_spl
+    lspl = l_spl
+#else
+    on = 0
+    rspl_out = 0.0d0
+    c1 = 0.0d0
+    lspl = 0.0d0
+#endif
+  end subroutine ref_get_sponge
 
   ! Load pressures, then derive q and the constraint scalars exactly as
   ! the reference main program does at start-up (src/q-gcm.F:711-731).

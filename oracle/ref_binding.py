@@ -27,6 +27,10 @@ CONFIGS = {
     # box_tiny compiled with the specified-temperature southern boundary of the mixed layer (-Dsb_hflux,
     # as examples/double_gyre_coupled; src/omlsubs.F:405-422)
     "box_tiny_sb": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsb_hflux"),
+    # the tiny grids compiled with the fork's sponge layer (-Dsponge_layer_k247: src/qgosubs.F:203-205, ramp
+    # src/q-gcm.F:1154-1168, constants src/parameters_data.F:140-144)
+    "box_tiny_spl": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsponge_layer_k247"),
+    "cyc_tiny_spl": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1, "-Dsponge_layer_k247"),
     "cyc_tiny": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1),
     "cyc_small": (6, 10, "nxta", 4, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
     "box_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0),
@@ -214,6 +218,13 @@ class RefLib:
         run_big_stack(self.lib.ref_valids, C.byref(ok), _dp(d))
         return bool(ok.value)
 
+    def get_sponge(self):
+        """(on, r_spl(nxpo, nypo), c1_spl, l_spl) of the build (on = False without -Dsponge_layer_k247)."""
+        on, c1, ls = C.c_int(), C.c_double(), C.c_double()
+        r = self._f2()
+        self.lib.ref_get_sponge(C.byref(on), _dp(r), C.byref(c1), C.byref(ls))
+        return bool(on.value), r, c1.value, ls.value
+
     def set_cyc_forcing(self, txis, txin, enis=None, enin=None):
         es = np.zeros(self.nl - 1) if enis is None else np.ascontiguousarray(enis, dtype=np.float64)
         en = np.zeros(self.nl - 1) if enin is None else np.ascontiguousarray(enin, dtype=np.float64)
@@ -388,6 +399,12 @@ class RefAtmos:
     def set_scalars(self, s):
         s = np.ascontiguousarray(s, dtype=np.float64)
         self.lib.ref_atm_set_scalars(_dp(s))
+
+    def get_monitors(self):
+        """(ermasa, emfrat) of the last atinvq (MODULE monitor; src/atisubs.F:236-248)."""
+        e, f = np.zeros(self.nl - 1), np.zeros(self.nl - 1)
+        self.lib.ref_atm_get_monitors(_dp(e), _dp(f))
+        return e, f
 
     def get_bsums(self):
         """ajisat, ajinat, ap5sat, ap5nat (nla each) of the last qgastep."""

@@ -73,7 +73,6 @@ __device__ __forceinline__ void cyc_bsums_block(const QgCycSumParams &P, int bid
   double s5 = 0.0, s9 = 0.0, s3 = 0.0, s5d = 0.0, sb = 0.0;
   const int per = (nx + BSUM_NB - 1) / BSUM_NB;
   const int ibeg = 1 + slice * per, iend = min(nx, ibeg + per - 1);
-  // (the first 256 threads work: k_tend_stream's workgroups of three layers have 384)
   for (int i = tid < 256 ? ibeg + tid : iend + 1; i <= iend; i += 256) {
     // Jacobian sums: weights 0.5 at i = 1 and i = nx (the same point), 1 inside
     const double wgt = (i == 1 || i == nx) ? 0.5 : 1.0;

@@ -304,7 +304,7 @@ struct QgOmlFinal {
 // one workgroup of OML_NT threads; red: 20 doubles of LDS
 __device__ __forceinline__ void oml_final_block(const QgOmlFinal &P, double *red, int tid) {
   double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const int first = tid < OML_NT ? tid : (1 << 30); // threads beyond OML_NT (k_tend_stream: 384) only keep the barrier
+  const int first = tid < OML_NT ? tid : (1 << 30); // threads beyond OML_NT only keep the barrier
   for (int k = first; k < P.nblkB; k += OML_NT) {
     a[0] += P.partB[k];
     a[1] += P.partB[P.nblkB + k];

@@ -43,6 +43,8 @@
 #define TEND_NT 256
 #endif
 
+static_assert(TEND_TX % 2 == 0, "tend_point<.., PAIR> stores the new qo in pairs of neighbouring columns: tiles start on odd columns");
+
 template <bool CYC>
 __device__ __forceinline__ int tend_wrap(int gi, int nxt) {
   if (CYC) {
@@ -111,6 +113,9 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
     double qn = qm[k] + P.tdto * qdot[k]; // qom + tdto*qdot
+    // sponge layer of the k247 fork (src/qgosubs.F:203-205), association as written there; a wave-uniform branch on a
+    // kernel argument, not taken in any BASELINE configuration
+    if (P.rspl) qn = qn + P.tdc1 * P.rspl[valid ? o : 0] * (qm[k] - betay);
     if (PAIR) {
       // (rows not stepped keep qo, qgosubs.F:214-219; o is even on even lanes: the tile starts at an odd column)
       qg_pair_store_wt(P.qnew + fs * k + o, wallrow ? qo[k] : qn, valid);

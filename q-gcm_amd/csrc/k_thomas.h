@@ -111,6 +111,7 @@ template <int R, int PHASE, bool CYCA = false, int KW = TH_KW>
 // generations - NAtl 1 km: 900 workgroups - gain a quarter: 29 -> 21 us.  PHASE 2 at 64 VGPRs spills: 50 -> 70 us.)
 __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8 : ((KW == 8 && R <= 16) ? 4 : 1)) void k_thomas(const QgThomasParams P) {
   static_assert(TH_KW % KW == 0, "a workgroup's wavenumbers lie inside one block of the pivot tables");
+  static_assert(KW % 2 == 0, "the write-through stores pair the lanes of neighbouring wavenumbers");
   // pitch TH_KW + 1: the scans read / write these arrays transposed ([lane][wv]: 64 lanes at a stride of one row);
   // at a pitch of 16 doubles = 128 B every lane hit the same pair of banks (SQ_LDS_BANK_CONFLICT was 55 % of the
   // kernel's LDS cycles)

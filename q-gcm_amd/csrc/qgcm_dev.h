@@ -126,6 +126,11 @@ struct QgTendParams {
   // rows; else this launch does the tile rows trow0 + r*tstride, r = 0..trows-1, and carries no edge / line-sum
   // workgroups unless the host appended them to the grid (they belong to the launch that follows the halo rows)
   int trow0, trows, tstride;
+  // the fork's sponge layer (-Dsponge_layer_k247, src/qgosubs.F:203-205): the leapfrog step gains
+  // + tdto*c1_spl*r_spl(i,j)*(qom - beta*yporel(j)); rspl = the ramp r_spl(nxpo,nypo) (field layout), tdc1 = tdto*c1_spl.
+  // nullptr (every BASELINE configuration): the term is absent
+  const double *rspl;
+  double tdc1;
 };
 
 struct QgDstParams {

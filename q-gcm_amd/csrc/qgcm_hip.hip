@@ -8,12 +8,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <vector>
 
 #include "qgcm_dev.h"
 #include "k_tend.h"
-#include "k_tend_stream.h"
 #include "k_dst.h"
 #include "k_fft3.h"
 // the row lengths with a three-stage plan: NAtl 1 km (4800), SOcn 5 km (4608), and two more for the tests
@@ -62,6 +62,8 @@ struct qgcm_hip_ctx {
   double *p[2], *q[2];
   int ip, iq; // p[ip] = po, p[ip^1] = pom ; q[iq] = qo, q[iq^1] = qom
   double *wekpo, *entoc, *ddynoc, *ochom, *yporel;
+  double *rspl = nullptr; // sponge-layer ramp r_spl (qgcm_hip_set_sponge), or nullptr
+  double c1_spl = 0.0;
   double *wrk, *rowsum;
   double *ybnd = nullptr;                  // cyclic y-slabs: (2, nl) zonal-mean solution next to the zonal boundaries (k_thomas PHASE 2)
   const double *slab_gath = nullptr;       // cyclic y-slabs: the gathered step messages of the last thomas phase 2
@@ -92,7 +94,6 @@ struct qgcm_hip_ctx {
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
-  bool tend_stream;       // the register-streaming tendency kernel (k_tend_stream.h); QGCM_HIP_TEND_TILES=1: the LDS-tile kernel (A/B + tests)
   std::vector<double> bd2oc;
   // profiling
   hipError_t timer_err = hipSuccess;
@@ -104,7 +105,9 @@ struct qgcm_hip_ctx {
   double kms[KN_COUNT];
   int klaunch[KN_COUNT];
   // graphs keyed by (ip, iq, phase)
-  std::map<long long, hipGraphExec_t> graphs;
+  struct GraphEntry { hipGraphExec_t exec; unsigned long used; }; // used: the steps_impl call that last replayed it
+  std::map<long long, GraphEntry> graphs;
+  unsigned long graph_call = 0;
   int avg_period = 25; // time levels are averaged after steps s with (s-1) mod avg_period == 0: ocean 25, atmosphere 100
   // ocean mixed layer (qgcm_hip_oml_init): three rotating sst buffers (is = sst, ism = sstm, spare = 3-is-ism)
   struct {
@@ -140,7 +143,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static void drop_graphs(qgcm_hip_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->graphs.empty() && c->slab_graphs.empty()) return;
-  for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+  for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second);
   c->graphs.clear();
   c->slab_graphs.clear();
@@ -232,6 +235,15 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   g.ldw = round_up(g.nxt + 1, 16);
   g.fstride = (long)g.ldx * g.ny;
   g.wstride = (long)g.ldw * g.ny;
+  // Layout invariants of the 16-byte write-through pair stores (qg_store16_wt / qg_pair_store_wt, qgcm_dev.h): pairs
+  // start on 16-byte boundaries (even pitches and strides), an odd row length leaves a padding column for the last
+  // pair's second half, and the work array has one behind the last coefficient.  They hold for the pitches chosen
+  // above; a later change of the layout must not break them silently.  (Row padding then holds garbage: nothing may
+  // read or reduce over columns >= nx resp. >= nk.)
+  if (g.ldx % 2 || g.ldw % 2 || g.fstride % 2 || g.wstride % 2 || (g.nx % 2 && g.ldx <= g.nx) || g.ldw <= g.nk)
+    QG_FAIL("qgcm_hip_create: row pitches ldx=%d ldw=%d break the alignment / padding rules of the paired stores", g.ldx, g.ldw);
+  if ((double)g.fstride * g.nl >= 2147483647.0 || (double)g.wstride * g.nl >= 2147483647.0)
+    QG_FAIL("qgcm_hip_create: %ld x %d elements per field exceed the kernels' 32-bit element offsets", g.fstride, g.nl);
   HIPCHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const size_t F = (size_t)g.fstride, W = (size_t)g.wstride;
   for (int i = 0; i < 2; ++i) {
@@ -262,8 +274,6 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     c->no_fused_unpack = f && f[0] == '1';
     const char *fc = getenv("QGCM_HIP_NO_FUSED_CONSTR");
     c->no_fused_constr = fc && fc[0] == '1';
-    const char *tt = getenv("QGCM_HIP_TEND_STREAM");
-    c->tend_stream = tt && tt[0] == '1';
   }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
@@ -277,7 +287,7 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
 extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   if (!c) return 0;
   hipStreamSynchronize(c->stream);
-  for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+  for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto &kv : c->slab_graphs) hipGraphExecDestroy(kv.second);
   if (c->sc_comm) {
     QgSlabComm *m = c->sc_comm;
@@ -290,7 +300,7 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
       if (p) hipFree(p);
     delete m;
   }
-  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath, c->area_part, c->area_out, c->ybnd};
+  double *vp[] = {c->val_part, c->val_out, c->dtopoc, c->th_cgath, c->area_part, c->area_out, c->ybnd, c->rspl};
   for (double *p : vp)
     if (p) hipFree(p);
   double *omp[] = {c->oml.sst[0], c->oml.sst[1], c->oml.sst[2], c->oml.fnet, c->oml.wekto, c->oml.xfo,
@@ -621,6 +631,24 @@ extern "C" int qgcm_hip_set_forcing(qgcm_hip_handle c, const double *wekpo, cons
   return 0;
 }
 
+// The fork's sponge layer (-Dsponge_layer_k247): r_spl(nxpo,nypo) of MODULE occonst (set by the main program,
+// src/q-gcm.F:1154-1168) and the compile-time constant c1_spl (src/parameters_data.F:144).  NULL switches the term off.
+extern "C" int qgcm_hip_set_sponge(qgcm_hip_handle c, const double *r_spl, double c1_spl) {
+  if (!c) QG_FAIL("qgcm_hip_set_sponge: null handle");
+  if (c->g.atm) QG_FAIL("qgcm_hip_set_sponge: the atmosphere has no sponge term (src/qgasubs.F)");
+  drop_graphs(c); // captured steps hold the kernel parameters by value
+  const QgGeom &g = c->g;
+  if (!r_spl) {
+    if (c->rspl) HIPCHECK(hipFree(c->rspl));
+    c->rspl = nullptr;
+    c->c1_spl = 0.0;
+    return 0;
+  }
+  if (!c->rspl && dalloc(&c->rspl, (size_t)g.fstride)) return 1;
+  c->c1_spl = c1_spl;
+  return upload2d(c, c->rspl, g.ldx, r_spl, g.nx, g.ny);
+}
+
 extern "C" int qgcm_hip_set_cyc_forcing(qgcm_hip_handle c, double txisoc, double txinoc, const double *enisoc,
                                         const double *eninoc) {
   if (!c) QG_FAIL("qgcm_hip_set_cyc_forcing: null handle");
@@ -799,6 +827,8 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   }
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctl2m[i] = pr.ctl2moc[i];
   P.upd_dpi = upd_dpi ? 1 : 0;
+  P.rspl = c->rspl;
+  P.tdc1 = pr.tdto * c->c1_spl; // tdto*c1_spl, src/qgosubs.F:204
   for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
   const TendTiling T = g.cyc ? tend_tiling<true>(g) : tend_tiling<false>(g);
   if (part != TEND_ALL && T.gy < 3) QG_FAIL("k_tend: a slab of fewer than three tile rows cannot be split");
@@ -817,29 +847,6 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   }
   QgOmlFinal F;
   fill_oml_final(c, F, oml_final && c->oml.on && part != TEND_OUTER);
-  if (c->tend_stream) {
-    // the register-streaming kernel (k_tend_stream.h): units of (58-column strip) x (16-row tile row), all layers
-    const TsTiling Ts = g.cyc ? ts_tiling<true>(g) : ts_tiling<false>(g);
-    const int nunits = Ts.gx * (part == TEND_ALL ? Ts.gy : P.trows);
-    const int nex = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : Ts.nedge);
-    KTimer t(c, KN_TEND);
-#define QG_TENDS(NLV)                                                                                         \
-  {                                                                                                           \
-    const int nwg = (nunits + TsCfg<NLV>::SPW - 1) / TsCfg<NLV>::SPW;                                         \
-    const dim3 grid(8 * ((nwg + 7) / 8) + nex);                                                               \
-    if (g.cyc) hipLaunchKernelGGL((k_tend_stream<NLV, true>), grid, dim3(TsCfg<NLV>::NT), 0, c->stream, P, S, F); \
-    else hipLaunchKernelGGL((k_tend_stream<NLV, false>), grid, dim3(TsCfg<NLV>::NT), 0, c->stream, P, S, F);       \
-  }
-    switch (g.nl) {
-      case 2: QG_TENDS(2); break;
-      case 3: QG_TENDS(3); break;
-      case 4: QG_TENDS(4); break;
-      default: QG_FAIL("k_tend_stream: unsupported nlo");
-    }
-#undef QG_TENDS
-    HIPCHECK(hipGetLastError());
-    return 0;
-  }
   const int nextra = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : T.nedge);
   dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
@@ -1839,13 +1846,22 @@ static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
   const long long key = ((long long)B << 32) | (omk << 24) | (c->ip << 16) | (c->iq << 8) | phase;
   auto it = c->graphs.find(key);
   if (it != c->graphs.end()) {
-    *out = it->second;
+    it->second.used = c->graph_call;
+    *out = it->second.exec;
     return 0;
   }
   if (c->graphs.size() >= kMaxGraphs) {
+    // evict what the CURRENT call has not touched (a dry pass that builds the graphs of a timed call must not lose
+    // them to its own later blocks); least recently used first, down to half the cache
     HIPCHECK(hipStreamSynchronize(c->stream)); // replays of the graphs about to be destroyed may still be queued
-    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
-    c->graphs.clear();
+    std::vector<std::pair<unsigned long, long long>> old;
+    for (auto &kv : c->graphs)
+      if (kv.second.used != c->graph_call) old.push_back({kv.second.used, kv.first});
+    std::sort(old.begin(), old.end());
+    for (size_t i = 0; i < old.size() && c->graphs.size() > kMaxGraphs / 2; ++i) {
+      hipGraphExecDestroy(c->graphs[old[i].second].exec);
+      c->graphs.erase(old[i].second);
+    }
   }
   hipGraph_t graph;
   const int ip0 = c->ip, iq0 = c->iq, is0 = c->oml.is, ism0 = c->oml.ism;
@@ -1864,7 +1880,7 @@ static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
   HIPCHECK(hipGraphDestroy(graph));
   // (the first replay of a fresh executable graph otherwise pays for its upload inside the caller's window)
   if (hipGraphUpload(exec, c->stream) != hipSuccess) (void)hipGetLastError();
-  c->graphs[key] = exec;
+  c->graphs[key] = {exec, c->graph_call};
   *out = exec;
   return 0;
 }
@@ -1872,6 +1888,7 @@ static int get_graph(qgcm_hip_ctx *c, int s0, int B, hipGraphExec_t *out) {
 // dry = true only instantiates the graphs the run will replay (so that a timed region does not pay for it)
 static int steps_impl(qgcm_hip_ctx *c, int s0, int n, bool dry) {
   int s = s0;
+  if (!dry) c->graph_call++; // (a dry pass belongs to the call that follows it: qgcm_hip_time_steps, prepare + steps)
   const int is0 = c->oml.is, ism0 = c->oml.ism;
   while (!c->profiling && n >= 2) {
     const int B = n >= kGraphBlock50 ? kGraphBlock50 : (n & ~1);
@@ -2029,6 +2046,22 @@ extern "C" int qgcm_hip_wrk_fill(qgcm_hip_handle c, double value) {
   hipLaunchKernelGGL(k_fill_rows, dim3((g.nk + 255) / 256, g.jr1 - g.jr0 + 1, g.nl), dim3(256), 0, c->stream, c->wrk,
                      g.wstride, g.ldw, g.nk, g.jr0, g.jr1, g.nl, value);
   HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// counterpart of qgcm_hip_wrk_get: the rows jr0..jr1 of a (nxpo, nyl, nlo) host block into the work array (box: the
+// interior columns 2..nxpo-1; cyclic: columns 1..nxto), everything else of the work array zero
+extern "C" int qgcm_hip_wrk_set(qgcm_hip_handle c, const double *wrk) {
+  if (check_ready(c, "qgcm_hip_wrk_set")) return 1;
+  if (!wrk) QG_FAIL("qgcm_hip_wrk_set: null argument");
+  const QgGeom &g = c->g;
+  HIPCHECK(hipMemsetAsync(c->wrk, 0, sizeof(double) * g.wstride * g.nl, c->stream));
+  const int coff = g.cyc ? 0 : 1;
+  for (int m = 0; m < g.nl; ++m)
+    HIPCHECK(hipMemcpy2DAsync(c->wrk + g.wstride * m + (size_t)(g.jr0 - 1) * g.ldw, (size_t)g.ldw * 8,
+                              wrk + (size_t)g.nx * g.ny * m + (size_t)(g.jr0 - 1) * g.nx + coff, (size_t)g.nx * 8, (size_t)g.nk * 8,
+                              (size_t)(g.jr1 - g.jr0 + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -7,6 +7,7 @@
 #
 #   build_dropin.sh <cfg> <nxta> <nyta> <nxaooc|nxta> <nyaooc> <ndxr> <nlo> <fnot> <beta> <mode>
 #       mode: box | cyclic | coupled      ->  -Docean_only | -Docean_only -Dcyclic_ocean -Dnb_hflux | (coupled) -Dsb_hflux
+#             box_spl = box + -Dsponge_layer_k247 (the fork's sponge layer, src/qgosubs.F:203-205)
 #
 # Nothing is copied into the repository: all outputs (objects, .mod, the two executables) go to
 # q-gcm_amd/fortran/_dropin/<cfg>/, which is git-ignored; the patched copy of the main program is deleted after it
@@ -32,9 +33,10 @@ fi
 
 case "$MODE" in
   box)     Q="-Docean_only -Dsb_hflux" ;;
+  box_spl) Q="-Docean_only -Dsb_hflux -Dsponge_layer_k247" ;;
   cyclic)  Q="-Docean_only -Dcyclic_ocean -Dnb_hflux" ;;
   coupled) Q="-Dsb_hflux" ;;
-  *) echo "mode must be box | cyclic | coupled" >&2; exit 2 ;;
+  *) echo "mode must be box | box_spl | cyclic | coupled" >&2; exit 2 ;;
 esac
 
 FCB="$FC -ffixed-line-length-132 -O2"
@@ -51,6 +53,7 @@ common() {
   # (c1_spl, l_spl: the fork's sponge-layer constants of src/parameters_data.F:140-144, which src/out_param.f:270-272
   #  prints; the example's parameters file predates them - SURVEY.md 8c)
   $FCO -c parameters_data.F
+  rm -f parameters_data.F   # edited text of a reference source: it does not stay in a directory that travels
   for f in atconst occonst athomog ochomog atstate ocstate intrfac; do $FCO $Q -c -I"$SRC" "$SRC/${f}_data.F"; done
   $FCO -c -I"$SRC" "$SRC/radiate_data.F"
   $FCO $Q -c -I"$SRC" "$SRC/timinfo_data.F"

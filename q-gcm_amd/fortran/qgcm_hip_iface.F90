@@ -67,6 +67,15 @@ module qgcm_hip_iface
       real(c_double), intent(in) :: pch1oc(*), pch2oc(*), pbhoc(*), aipcho(*), hc1soc(*), hc2soc(*), hc1noc(*), hc2noc(*)
       real(c_double), value :: hbsioc, aipbho
     end function
+    integer(c_int) function qgcm_hip_abi_version() bind(C, name='qgcm_hip_abi_version')
+      import :: c_int
+    end function
+    integer(c_int) function qgcm_hip_set_sponge(h, r_spl, c1_spl) bind(C, name='qgcm_hip_set_sponge')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: r_spl(*)
+      real(c_double), value :: c1_spl
+    end function
     integer(c_int) function qgcm_hip_set_cyc_forcing(h, txisoc, txinoc, enisoc, eninoc) bind(C, name='qgcm_hip_set_cyc_forcing')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
@@ -275,6 +284,17 @@ module qgcm_hip_iface
 contains
 
   ! The reference's error convention is print + stop (e.g. src/ocisubs.F:361-365).
+  ! QGCM_HIP_ABI_VERSION of include/qgcm_hip.h this interface block was written against: an older libqgcm_hip.so
+  ! (without qgcm_hip_get_monitors / qgcm_hip_set_sponge, or with the other halo default) must not be driven by it
+  subroutine qgcm_hip_check_abi
+    integer(c_int), parameter :: want = 3
+    if (qgcm_hip_abi_version() /= want) then
+      print *, ' qgcm_hip: libqgcm_hip.so has ABI version ', qgcm_hip_abi_version(), ', this host binds version ', want
+      print *, ' program terminates'
+      stop 1
+    endif
+  end subroutine qgcm_hip_check_abi
+
   subroutine qgcm_hip_check(rc, where)
     integer(c_int), intent(in) :: rc
     character(len=*), intent(in) :: where

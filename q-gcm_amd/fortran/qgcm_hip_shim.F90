@@ -18,9 +18,8 @@
 !
 ! Build with the same cpp macros as the reference (-Docean_only ...).
 !-----------------------------------------------------------------------
-#ifdef sponge_layer_k247
-#error "qgcm_hip_shim: -Dsponge_layer_k247 (the sponge term of the leapfrog step, src/qgosubs.F:70-72,175-205) is not built on the device path: it is off in every BASELINE configuration; build without it"
-#endif
+! -Dsponge_layer_k247 (the fork's sponge term of the leapfrog step, src/qgosubs.F:70-72,175-205): the ramp r_spl
+! the main program sets (src/q-gcm.F:1154-1168) and c1_spl go to the device with the first push of the state.
 module qgcm_hip_state
   use iso_c_binding
   use qgcm_hip_iface
@@ -57,6 +56,7 @@ contains
     type(qgcm_hip_params) :: p
     integer :: k, l
     if (c_associated(qgcm_hip_handle)) return
+    call qgcm_hip_check_abi
     p%nxpo = nxpo; p%nypo = nypo; p%nlo = nlo
 #ifdef cyclic_ocean
     p%cyclic = 1
@@ -118,6 +118,9 @@ contains
 #endif
     call qgcm_hip_check(qgcm_hip_set_scalars(qgcm_hip_handle, scal), 'qgcm_hip_set_scalars')
     call qgcm_hip_push_forcing
+#ifdef sponge_layer_k247
+    call push_sponge
+#endif
     qgcm_hip_device_owns = .true.
   end subroutine qgcm_hip_push
 
@@ -129,6 +132,19 @@ contains
     call push_cyc
 #endif
   end subroutine qgcm_hip_push_forcing
+
+#ifdef sponge_layer_k247
+  ! r_spl (MODULE occonst) is set late in the main program's set-up (src/q-gcm.F:1154-1168), before the time loop;
+  ! sent once - it does not change afterwards
+  subroutine push_sponge
+    use parameters, only : c1_spl
+    use occonst, only : r_spl
+    logical, save :: sent = .false.
+    if (sent) return
+    call qgcm_hip_check(qgcm_hip_set_sponge(qgcm_hip_handle, r_spl, c1_spl), 'qgcm_hip_set_sponge')
+    sent = .true.
+  end subroutine push_sponge
+#endif
 
 #ifdef cyclic_ocean
   ! line integrals that xforc (txisoc/txinoc) and oml (enisoc/eninoc) maintain, src/ochomog_data.F

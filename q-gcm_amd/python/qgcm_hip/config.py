@@ -31,6 +31,10 @@ class OceanConfig:
     ah4oc: Tuple[float, ...] = (2.0e9, 2.0e9, 2.0e9)
     hoc: Tuple[float, ...] = (350.0, 750.0, 2900.0)
     gpoc: Tuple[float, ...] = (0.015, 0.0075)
+    # the fork's sponge layer (cpp option sponge_layer_k247; constants of src/parameters_data.F:140-144):
+    # l_spl = 0 means the option is not defined (every BASELINE configuration)
+    c1_spl: float = 0.0
+    l_spl: float = 0.0
 
     # derived grid parameters, src/parameters_data.F (nxto = ndxr*nxaooc, ...)
     @property
@@ -184,6 +188,11 @@ PRESETS = {
     "box_tiny2": OceanConfig("box_tiny2", 8, 8, 5, 4, 6, 2, fnot=5.92e-05, beta=2.08e-11, cyclic=False,
                              dxo=1.0e5, dta=720.0, ah2oc=(0.0, 0.0), ah4oc=(3.2e12, 3.2e12),
                              hoc=(500.0, 3500.0), gpoc=(0.02,)),
+    # ... and compiled with -Dsponge_layer_k247 (src/qgosubs.F:203-205): own reference builds box_tiny_spl / cyc_tiny_spl
+    "box_tiny_spl": OceanConfig("box_tiny_spl", 8, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
+                                ah4oc=(3.2e12,) * 3, c1_spl=-2.5e-5, l_spl=4.0e5, **_NATL),
+    "cyc_tiny_spl": OceanConfig("cyc_tiny_spl", 4, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
+                                ah4oc=(3.2e12,) * 3, c1_spl=-2.5e-5, l_spl=4.0e5, **_SOCN),
     # nxto = 192 = 64*3: exercises the wave-per-row-pair DST kernel at a size the oracle runs in seconds
     "box_med": OceanConfig("box_med", 16, 10, 12, 6, 16, 3, dxo=2.5e4, dta=240.0,
                            ah4oc=(1.2e10,) * 3, **_NATL),
@@ -191,6 +200,13 @@ PRESETS = {
                             ah4oc=(3.2e12,) * 3, **_SOCN),
     "cyc_small": OceanConfig("cyc_small", 6, 10, 6, 4, 16, 3, dxo=5.0e4, dta=360.0,
                              ah4oc=(2.0e11,) * 3, **_SOCN),
+    # the tiny grids with the Laplacian-viscosity (Del-4th of p) term switched on, a different value per layer
+    # (src/qgosubs.F:375-377; ah2oc = 0 in every example of the reference: this is the only pin of that branch and of
+    # the cyclic ap3soc / ap3noc sums, src/qgosubs.F:429-443).  Same reference builds as box_tiny / cyc_tiny.
+    "box_tiny_ah2": OceanConfig("box_tiny_ah2", 8, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
+                                ah2oc=(240.0, 160.0, 80.0), ah4oc=(3.2e12,) * 3, **_NATL),
+    "cyc_tiny_ah2": OceanConfig("cyc_tiny_ah2", 4, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
+                                ah2oc=(240.0, 160.0, 80.0), ah4oc=(3.2e12,) * 3, **_SOCN),
     # nxto = 192 = 64*3 and 960 = 64*15: exercise the wave-per-row-pair real-FFT kernels (k_rfft64.h) of the cyclic path
     "cyc_med": OceanConfig("cyc_med", 12, 10, 12, 4, 16, 3, dxo=2.5e4, dta=240.0, ah4oc=(1.2e10,) * 3, **_SOCN),
     "cyc_960": OceanConfig("cyc_960", 60, 12, 60, 3, 16, 3, dxo=5.0e3, **_SOCN),

@@ -88,6 +88,19 @@ def bd2oc(cfg):
     return aoc, b
 
 
+def sponge_ramp(cfg):
+    """r_spl(nxpo, nypo) of a -Dsponge_layer_k247 build (src/q-gcm.F:1154-1168, option nospl_in_ewbdy_k247 not
+    defined): exp(-2 pi (d_y / l_spl)^2) + exp(-2 pi (d_x / l_spl)^2) with d = half the (grid-point count x spacing)
+    minus the distance of the 1-based index from it."""
+    pi = 3.14159265358979324  # src/q-gcm.F:89
+
+    def ramp(n, dx):
+        idx = np.arange(1, n + 1, dtype=np.float64)
+        d = 0.5 * dx * float(n) - np.abs(dx * idx - 0.5 * dx * float(n))
+        return np.exp(-2.0 * pi * (d / cfg.l_spl) ** 2.0)
+    return np.asfortranarray(ramp(cfg.nxpo, cfg.dxo)[:, None] + ramp(cfg.nypo, cfg.dyo)[None, :])
+
+
 def xintp(v):
     """Area integral with weights 1 / 0.5 (edges) / 0.25 (corners), intsubs.f:78-133."""
     v = np.asarray(v)

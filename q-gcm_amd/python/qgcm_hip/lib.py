@@ -4,6 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MAXL = 8
+ABI_VERSION = 3  # QGCM_HIP_ABI_VERSION of include/qgcm_hip.h
 
 
 class QgcmHipError(RuntimeError):
@@ -44,12 +45,12 @@ class OmlParams(C.Structure):
 SYMBOLS = [
     "qgcm_hip_create", "qgcm_hip_destroy", "qgcm_hip_last_error", "qgcm_hip_abi_version",
     "qgcm_hip_set_grid", "qgcm_hip_set_geometry", "qgcm_hip_set_homog_box", "qgcm_hip_set_homog_cyc",
-    "qgcm_hip_set_state", "qgcm_hip_get_state", "qgcm_hip_set_forcing", "qgcm_hip_set_cyc_forcing",
+    "qgcm_hip_set_state", "qgcm_hip_get_state", "qgcm_hip_set_forcing", "qgcm_hip_set_cyc_forcing", "qgcm_hip_set_sponge",
     "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag", "qgcm_hip_get_monitors",
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_ocqbdy_host",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
     "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps",
-    "qgcm_hip_wrk_fill", "qgcm_hip_wrk_get", "qgcm_hip_area_integrals",
+    "qgcm_hip_wrk_fill", "qgcm_hip_wrk_get", "qgcm_hip_wrk_set", "qgcm_hip_area_integrals",
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
     "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
     "qgcm_hip_constr", "qgcm_hip_unpack",
@@ -77,6 +78,9 @@ def load_library():
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
     L.qgcm_hip_last_error.restype = C.c_char_p
+    if L.qgcm_hip_abi_version() != ABI_VERSION:
+        raise QgcmHipError("%s has ABI version %d, this package binds version %d (include/qgcm_hip.h) - rebuild it"
+                           % (path, L.qgcm_hip_abi_version(), ABI_VERSION))
     L.qgcm_hip_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
     L.qgcm_hip_destroy.argtypes = [vp]
     L.qgcm_hip_set_grid.argtypes = [vp, dp, dp, dp]
@@ -87,6 +91,7 @@ def load_library():
     L.qgcm_hip_get_state.argtypes = [vp, dp, dp, dp, dp]
     L.qgcm_hip_set_forcing.argtypes = [vp, dp, dp, dp]
     L.qgcm_hip_set_cyc_forcing.argtypes = [vp, C.c_double, C.c_double, dp, dp]
+    L.qgcm_hip_set_sponge.argtypes = [vp, dp, C.c_double]
     L.qgcm_hip_set_scalars.argtypes = [vp, dp]
     L.qgcm_hip_get_scalars.argtypes = [vp, dp]
     L.qgcm_hip_get_inv_diag.argtypes = [vp, dp, dp]
@@ -105,6 +110,7 @@ def load_library():
     L.qgcm_hip_row_transform.argtypes = [vp, C.c_int]
     L.qgcm_hip_wrk_fill.argtypes = [vp, C.c_double]
     L.qgcm_hip_wrk_get.argtypes = [vp, dp]
+    L.qgcm_hip_wrk_set.argtypes = [vp, dp]
     L.qgcm_hip_area_integrals.argtypes = [vp, dp]
     L.qgcm_hip_thomas_msg_len.argtypes = [vp]
     L.qgcm_hip_thomas_const_len.argtypes = [vp]

@@ -84,6 +84,8 @@ class OceanModel:
             check(self.L.qgcm_hip_set_homog_box(self.h, *[_dp(a) for a in args]))
         self.nscal = 2 * (nl - 1) + 4 * nl
         self.step_index = 1  # next 1-based ocean step
+        if getattr(cfg, "l_spl", 0.0) > 0.0:  # a -Dsponge_layer_k247 configuration
+            self.set_sponge(hostinit.sponge_ramp(cfg), cfg.c1_spl)
 
     # -- life cycle ----------------------------------------------------------
     def close(self):
@@ -158,6 +160,16 @@ class OceanModel:
         es = np.zeros(nl - 1) if enisoc is None else np.ascontiguousarray(enisoc, dtype=np.float64)
         en = np.zeros(nl - 1) if eninoc is None else np.ascontiguousarray(eninoc, dtype=np.float64)
         check(self.L.qgcm_hip_set_cyc_forcing(self.h, float(txisoc), float(txinoc), _dp(es), _dp(en)))
+
+    def set_sponge(self, r_spl, c1_spl):
+        """The fork's sponge layer (src/qgosubs.F:203-205): ramp r_spl(nxpo, nypo) and the constant c1_spl;
+        r_spl = None switches the term off."""
+        if r_spl is None:
+            check(self.L.qgcm_hip_set_sponge(self.h, None, 0.0))
+            return
+        r = _f(r_spl)
+        assert r.shape == (self.cfg.nxpo, self.cfg.nypo)
+        check(self.L.qgcm_hip_set_sponge(self.h, _dp(r), float(c1_spl)))
 
     def set_scalars(self, s):
         s = np.ascontiguousarray(s, dtype=np.float64)
@@ -260,6 +272,20 @@ class OceanModel:
         d = np.zeros(5)
         check(self.L.qgcm_hip_oml_get_diag(self.h, _dp(e), _dp(d)))
         return e, d
+
+    # -- the row transforms by themselves (replacements of FFTPACK's dsint / drfftf / drfftb) -------------------
+    def wrk_set(self, wrk):
+        w = _f(wrk)
+        assert w.shape == (self.cfg.nxpo, self.cfg.nypo, self.cfg.nlo)
+        check(self.L.qgcm_hip_wrk_set(self.h, _dp(w)))
+
+    def wrk_get(self):
+        w = np.zeros((self.cfg.nxpo, self.cfg.nypo, self.cfg.nlo), order="F")
+        check(self.L.qgcm_hip_wrk_get(self.h, _dp(w)))
+        return w
+
+    def row_transform(self, inverse):
+        check(self.L.qgcm_hip_row_transform(self.h, int(inverse)))
 
     def helmholtz(self, wrk, boc):
         """hsbxoc / hscyoc replacement (src/ocisubs.F:415-618); returns the solution."""

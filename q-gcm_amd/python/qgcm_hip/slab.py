@@ -354,6 +354,12 @@ class HipSlab:
         check(self.L.qgcm_hip_get_scalars(self.h, _dp(s)))
         return s
 
+    def get_monitors(self):
+        """(ermaso, emfroc) of the last constraint solve of a zonally cyclic slab (every rank holds the same numbers)."""
+        e, f = np.zeros(self.cfg.nlo - 1), np.zeros(self.cfg.nlo - 1)
+        check(self.L.qgcm_hip_get_monitors(self.h, _dp(e), _dp(f)))
+        return e, f
+
     # slab kernels -------------------------------------------------------------
     def qgostep(self):
         check(self.L.qgcm_hip_qgostep(self.h)); self._done()

@@ -32,6 +32,8 @@ def apply_inputs(model, g, cfg):
     model.set_forcing(g["in_wekpo"], g["in_entoc"], g["in_xon"])
     if cfg.cyclic:
         model.set_cyc_forcing(float(g["in_txis"]), float(g["in_txin"]), g["in_enis"], g["in_enin"])
+    if "in_rspl" in g:  # the reference build's own ramp (its exp() need not round like numpy's)
+        model.set_sponge(g["in_rspl"], float(g["in_c1spl"]))
 
 
 def load_snapshot(model, g, tag):
@@ -57,10 +59,15 @@ def scal_err(model, g, tag, cfg):
     return float(e)
 
 
-CONFIG_NAMES = ("box_tiny", "box_tiny2", "box_small", "cyc_tiny", "cyc_small")
-BOX_NAMES = ("box_tiny", "box_tiny2", "box_small")
+# *_ah2: the tiny grids with ah2oc != 0 (the Del-4th-of-p viscosity term of src/qgosubs.F:375-377 and, cyclic, the
+# ap3soc / ap3noc boundary sums) - tests/golden/make_golden.py
+# *_spl: the tiny grids of reference builds with -Dsponge_layer_k247 (src/qgosubs.F:203-205)
+CONFIG_NAMES = ("box_tiny", "box_tiny2", "box_small", "cyc_tiny", "cyc_small", "box_tiny_ah2", "cyc_tiny_ah2",
+                "box_tiny_spl", "cyc_tiny_spl")
+BOX_NAMES = ("box_tiny", "box_tiny2", "box_small", "box_tiny_ah2", "box_tiny_spl")
 SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_small": (1, 30),
-         "cyc_tiny": (1, 2, 25, 26, 60), "cyc_small": (1, 30)}
+         "cyc_tiny": (1, 2, 25, 26, 60), "cyc_small": (1, 30), "box_tiny_ah2": (1, 2, 26), "cyc_tiny_ah2": (1, 2, 26),
+         "box_tiny_spl": (1, 2, 26), "cyc_tiny_spl": (1, 2, 26)}
 
 
 def preset(name):
@@ -144,3 +151,30 @@ def atm_scal_err(model, g, tag, acfg):
     e = np.abs(s[:2 * (nl - 1)] - r[:2 * (nl - 1)]).max() / scale
     den = np.abs(r[2 * (nl - 1):]).max()
     return float(max(e, np.abs(s[2 * (nl - 1):] - r[2 * (nl - 1):]).max() / den))
+
+
+def cpl_fullsize_inputs(g, oc, at):
+    """Inputs of tests/golden/cpl_natl5_sample.npz (make_golden_atmos.py coupled_fullsize): re-generated from
+    qgcm_hip.synth; the stored strided samples must be reproduced bit for bit."""
+    from qgcm_hip import synth
+    so, sa = int(g["stride_oc"]), int(g["stride"])
+    po = synth.gaussian_eddy(oc, noise=1.0e-3)
+    pom = np.asfortranarray(0.98 * po)
+    tx, ty = synth.wind_stress(oc)
+    _, wekpo = synth.wekpo_from_tau(oc, tx, ty)
+    for k, v in (("po", po), ("pom", pom), ("wekpo", wekpo)):
+        assert np.array_equal(v[::so, ::so], g["in_" + k]), "synthetic ocean input %s drifted from the fixture" % k
+    f = synth.atmos_fields(at)
+    for k in ("pa", "pam", "wekpa", "entat", "ddynat"):
+        assert np.array_equal(f[k][::sa, ::sa], g["in_" + k]), "synthetic atmosphere input %s drifted from the fixture" % k
+    for k in ("xan", "txis", "txin", "enis", "enin"):
+        assert np.array_equal(np.asarray(f[k]), g["in_" + k]), k
+    return po, pom, wekpo, f
+
+
+def cpl_fullsize_errs(ocean, atmos, g, nt):
+    so = int(g["stride_oc"])
+    e = {n: float(np.abs(ocean.get_state()[i][::so, ::so] - g["nt%d_%s" % (nt, n)]).max() / float(g["nt%d_%s_max" % (nt, n)]))
+         for i, n in enumerate(FIELDS)}
+    e.update(atm_state_errs(atmos, g, "nt%d" % nt))
+    return e

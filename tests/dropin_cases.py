@@ -15,7 +15,9 @@ NSTEPS = 120
 # Measured on the MI355X in round 3 (one OpenMP thread for the coupled case, gpurun_out/dropin_errors.log): box 7.6e-15,
 # cyclic 8e-16, coupled from rest 2.7e-11 after 120 ocean steps (round 2 allowed 2e-2 on the strength of the
 # reference's own 1-vs-5-thread spread; on ONE thread both executables are reproducible and agree this closely).
-RUNS = {"box_tiny": ((120, 1e-9),), "cyc_tiny": ((120, 1e-9),), "cpl_tiny": ((1, 1e-12), (120, 1e-8))}
+# box_tiny_spl (round 4): the box case compiled with -Dsponge_layer_k247 - the shim sends r_spl / c1_spl to the device
+RUNS = {"box_tiny": ((120, 1e-9),), "cyc_tiny": ((120, 1e-9),), "cpl_tiny": ((1, 1e-12), (120, 1e-8)),
+        "box_tiny_spl": ((120, 1e-9),)}
 # Round 3 pins the coupled OCEAN half: after one ocean step from radiative balance the ocean is still at rest (po = pom
 # = 0 on both sides), so (1, 1e-12) above checks the atmosphere and the mixed layers only - and for dozens of steps
 # after that po stays below 1e-8 m2/s2 and is driven by rounding noise (xon(1), "zero by construction of entoc in
@@ -30,13 +32,14 @@ RUNS_RESTART = {"cpl_tiny": ((4, 1e-12), (30, 1e-11))}
 # reproducible with two threads: two runs of the unmodified q-gcm_ref on the same case differ in pa / ast after ONE
 # ocean step (thread-order dependent sums in xforc / aml, amplified by the nearly singular barotropic zonal-mean mode
 # of the channel to ~1e-12) - observed as a flaky 1e-12 comparison.  One thread is reproducible, for both executables.
-THREADS = {"box_tiny": 2, "cyc_tiny": 2, "cpl_tiny": 1}
+THREADS = {"box_tiny": 2, "cyc_tiny": 2, "cpl_tiny": 1, "box_tiny_spl": 2}
 
 # cfg -> ((nxta, nyta, nxaooc, nyaooc, ndxr, nlo, fnot, beta), mode); dims as oracle/ref_binding.CONFIGS
 CASES = {
     "box_tiny": ((8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11"), "box"),
     "cyc_tiny": ((4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11"), "cyclic"),
     "cpl_tiny": ((16, 12, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11"), "coupled"),
+    "box_tiny_spl": ((8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11"), "box_spl"),
 }
 
 

@@ -32,7 +32,11 @@ import ref_binding  # noqa: E402
 from qgcm_hip import config, synth  # noqa: E402
 
 SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_small": (1, 30),
-         "cyc_tiny": (1, 2, 25, 26, 60), "cyc_small": (1, 30)}
+         "cyc_tiny": (1, 2, 25, 26, 60), "cyc_small": (1, 30),
+         "box_tiny_ah2": (1, 2, 26), "cyc_tiny_ah2": (1, 2, 26),
+         "box_tiny_spl": (1, 2, 26), "cyc_tiny_spl": (1, 2, 26)}
+# fixtures that differ from another one only in run-time parameters share its reference build
+REFCFG = {"box_tiny_ah2": "box_tiny", "cyc_tiny_ah2": "cyc_tiny"}
 
 
 def state_dict(r, tag, out):
@@ -43,8 +47,8 @@ def state_dict(r, tag, out):
 
 def make(name):
     cfg = config.preset(name)
-    ref_binding.build(name)
-    r = ref_binding.RefLib(name)
+    ref_binding.build(REFCFG.get(name, name))
+    r = ref_binding.RefLib(REFCFG.get(name, name))
     assert (r.nx, r.ny, r.nl, bool(r.cyclic)) == (cfg.nxpo, cfg.nypo, cfg.nlo, cfg.cyclic)
     assert r.fnot == cfg.fnot and r.beta == cfg.beta
     r.init(cfg.dxo, cfg.dto, cfg.delek, cfg.bccooc, cfg.ah2oc, cfg.ah4oc, cfg.hoc, cfg.gpoc)
@@ -66,6 +70,11 @@ def make(name):
     xon = np.zeros(nl - 1)
     xon[0] = 1.0e3
     out.update(in_po=po, in_pom=pom, in_wekpo=wekpo, in_entoc=entoc, in_xon=xon)
+    spl_on, rspl, c1, lspl = r.get_sponge()
+    assert spl_on == (cfg.l_spl > 0.0)
+    if spl_on:  # -Dsponge_layer_k247 build: its ramp (set as src/q-gcm.F:1154-1168 does) and constants are inputs
+        assert (c1, lspl) == (cfg.c1_spl, cfg.l_spl)
+        out.update(in_rspl=rspl, in_c1spl=np.array(c1), in_lspl=np.array(lspl))
     r.set_p(po, pom)
     r.set_forcing(wekpo, entoc, xon)
     if cfg.cyclic:
@@ -93,6 +102,10 @@ def make(name):
             done = s
         state_dict(r, "steps%d" % s, out)
     # ---- Helmholtz solver ------------------------------------------------
+    if name in REFCFG or spl_on:  # (the Helmholtz solver sees neither ah2oc nor the sponge: its vectors stay with the base fixture)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, "%d arrays" % len(out))
+        return r
     rhs = np.asfortranarray(rng.standard_normal((nx, ny)))
     boc = out["c_bd2oc"] - out["c_rdm2oc"][1]
     out["helm_rhs"], out["helm_boc"] = rhs, boc
@@ -132,9 +145,31 @@ def make_fft(r):
     print("wrote fftpack_eigmod")
 
 
+def make_fft_long(r):
+    """FFTPACK known-answer vectors at the row lengths of NAtl 1 km (dsint, n = 4799) and SOcn 5 km (drfftf / drfftb,
+    n = 4608) and at 960 / 4800 for the cyclic kernels; any reference build serves (FFTPACK does not depend on the grid)."""
+    rng = np.random.default_rng(12)
+    out = {}
+    for n in (4799,):
+        x = rng.standard_normal(n)
+        out["dsint_in_%d" % n] = x
+        out["dsint_out_%d" % n] = r.dsint(x)
+    for n in (960, 4608, 4800):
+        x = rng.standard_normal(n)
+        f = r.drfft(x, +1)
+        out["drfft_in_%d" % n] = x
+        out["drfftf_out_%d" % n] = f
+        out["drfftb_out_%d" % n] = r.drfft(f, -1)
+    np.savez_compressed(os.path.join(HERE, "fftpack_long.npz"), **out)
+    print("wrote fftpack_long")
+
+
 if __name__ == "__main__":
     # one process per config: the reference libraries export identical symbols
-    if len(sys.argv) == 2:
+    if len(sys.argv) == 2 and sys.argv[1] == "fft_long":
+        ref_binding.build("box_tiny")
+        make_fft_long(ref_binding.RefLib("box_tiny"))
+    elif len(sys.argv) == 2:
         r = make(sys.argv[1])
         if sys.argv[1] == "box_tiny":
             make_fft(r)

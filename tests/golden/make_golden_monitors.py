@@ -28,7 +28,36 @@ def inputs(cfg):
     return po, wek, txis, txin
 
 
+def make_atmos():
+    """The atmosphere's twins ermasa / emfrat (src/atisubs.F:236-248) from the coupled reference build cpl_tiny: the
+    synthetic atmosphere of qgcm_hip.synth.atmos_fields, whose prescribed xan is not consistent with the flow either;
+    after each of the first 6 atmospheric steps -> tests/golden/atm_tiny_monitors.npz (inputs: atm_tiny.npz)."""
+    import ref_binding
+    from qgcm_hip import config, synth
+    oc, at = config.preset("cpl_tiny"), config.atmos_preset("cpl_tiny")
+    ref_binding.build("cpl_tiny", force=True)   # (the harness gained ref_atm_get_monitors in round 4)
+    r = ref_binding.RefLib("cpl_tiny")
+    a = ref_binding.RefAtmos(r)
+    f = synth.atmos_fields(at)
+    r.init(oc.dxo, oc.dto, oc.delek, oc.bccooc, oc.ah2oc, oc.ah4oc, oc.hoc, oc.gpoc)
+    a.init(at.dxa, at.dta, at.bccoat, at.ah4at, at.hat, at.gpat, f["ddynat"])
+    a.homsol()
+    a.set_p(f["pa"], f["pam"])
+    a.set_forcing(f["wekpa"], f["entat"], f["xan"], f["txis"], f["txin"], f["enis"], f["enin"])
+    out = {}
+    for s in range(1, NSTEPS + 1):
+        a.steps(s, 1)
+        e, g = a.get_monitors()
+        out["step%d_ermasa" % s], out["step%d_emfrat" % s] = e, g
+        out["step%d_scal" % s] = a.get_scalars()
+    np.savez_compressed(os.path.join(HERE, "atm_tiny_monitors.npz"), **out)
+    sys.stderr.write("wrote atm_tiny_monitors.npz: ermasa %s emfrat %s\n" % (out["step6_ermasa"], out["step6_emfrat"]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "atmos":   # (one reference build per process)
+        make_atmos()
+        sys.exit(0)
     import ref_binding
     from qgcm_hip import config
     cfg = config.preset("cyc_tiny")

@@ -27,7 +27,9 @@ def test_library_exports_all_symbols(repo_root):
     for s in header_symbols(repo_root):
         assert hasattr(L, s), s
     L.qgcm_hip_abi_version.restype = ctypes.c_int
-    assert L.qgcm_hip_abi_version() == 2  # 2: qgcm_hip_params.atmos + the atmosphere entry points
+    assert L.qgcm_hip_abi_version() == lib.ABI_VERSION == 3  # changelog: include/qgcm_hip.h
+    hdr = open(os.path.join(repo_root, "include", "qgcm_hip.h")).read()
+    assert "#define QGCM_HIP_ABI_VERSION %d" % lib.ABI_VERSION in hdr
 
 
 def test_params_struct_layout():

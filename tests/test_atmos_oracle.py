@@ -150,3 +150,27 @@ def test_coupled_main_loop():
         assert all(v < 5e-12 for v in e.values()), (upto, e)
     o.close()
     a.close()
+
+
+def test_coupled_main_loop_full_size_sample():
+    """BASELINE configs[3] at full size: NAtl 5 km ocean (961 x 961 x 3) under the 385 x 97 x 3 atmosphere, the coupled
+    loop with the forcing held after three ocean steps (nt = 9) against samples of the coupled reference build itself."""
+    from common import cpl_fullsize_errs, cpl_fullsize_inputs
+    g = load_golden("cpl_natl5_sample")
+    oc, at = config.preset("cpl_natl5"), config.atmos_preset("cpl_natl5")
+    po, pom, wekpo, f = cpl_fullsize_inputs(g, oc, at)
+    o = make_oracle(oc)
+    a = ob.AtmosOracle(at.nxpa, at.nypa, at.nla, at.fnot, at.beta, at.dxa, at.dta, at.bccoat, at.ah4at, at.hat, at.gpat,
+                       at.yporel(), f["ddynat"])
+    o.set_p(po, pom)
+    o.set_forcing(wekpo)
+    atm_apply(a, f)
+    nstr = int(g["nstr"])
+    for nt in range(1, 10):
+        if nt % nstr == 1:
+            o.steps((nt - 1) // nstr + 1, 1)
+        a.steps(nt, 1)
+    e = cpl_fullsize_errs(o, a, g, 9)
+    assert all(v < 1e-11 for v in e.values()), e
+    o.close()
+    a.close()

@@ -32,8 +32,9 @@ def test_dropin_compiles_and_links(cfg):
     ldd = subprocess.run(["ldd", exe], stdout=subprocess.PIPE, text=True).stdout
     assert "libqgcm_hip.so" in ldd and "not found" not in ldd, ldd
     # nothing of the reference's source text stays behind in the build directory
-    left = [f for f in os.listdir(os.path.dirname(exe) + "/hip") if f.endswith((".F", ".f")) and f != "parameters_data.F"]
-    assert left == [], left
+    for sub in ("hip", "ref"):
+        left = [f for f in os.listdir(os.path.join(os.path.dirname(exe), sub)) if f.endswith((".F", ".f", ".F90"))]
+        assert left == [], (sub, left)
     # the replaced routines really come from the shim: the executable binds the C ABI, not FFTPACK-based solvers
     syms = subprocess.run(["nm", "-D", "--undefined-only", exe], stdout=subprocess.PIPE, text=True).stdout
     for s in ("qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_helmholtz", "qgcm_hip_lf_average"):

@@ -200,6 +200,61 @@ def test_coupled_main_loop_vs_reference():
     a.close()
 
 
+def test_atmosphere_continuity_monitors_vs_reference():
+    """ermasa / emfrat of atinvq (MODULE monitor, src/atisubs.F:236-248: est1 = aiplay(k) - aiplay(k+1)), which the
+    drop-in shim copies back with every pull: after each of six atmospheric steps against the coupled reference build
+    (tests/golden/atm_tiny_monitors.npz, make_golden_monitors.py atmos), stand-alone calls and qgcm_hip_steps."""
+    from qgcm_hip import AtmosModel
+    acfg = config.atmos_preset("cpl_tiny")
+    g, gm = load_golden("atm_tiny"), load_golden("atm_tiny_monitors")
+    f = atm_inputs(g, acfg)
+    for fused in (False, True):
+        m = AtmosModel(acfg, ddynat=f["ddynat"])
+        try:
+            atm_apply(m, f)
+            for s in range(1, 7):
+                if fused:
+                    m.steps(1, s0=s)
+                else:
+                    m.qgastep()
+                    m.atinvq()
+                    m.atqzbd()
+                    if (s - 1) % 100 == 0:
+                        m.lf_average()
+                e, fr = m.get_monitors()
+                sr = gm["step%d_scal" % s]
+                scale = np.abs(sr[:acfg.nla - 1]) + np.abs(sr[acfg.nla - 1:2 * (acfg.nla - 1)])  # |dpiat| + |dpiatp| ~ esum
+                assert (np.abs(e - gm["step%d_ermasa" % s]) / scale).max() < 1e-12, (fused, s, e, gm["step%d_ermasa" % s])
+                assert np.abs(fr - gm["step%d_emfrat" % s]).max() < 1e-11, (fused, s, fr, gm["step%d_emfrat" % s])
+                assert np.abs(gm["step%d_emfrat" % s]).min() > 1e-5   # the fixture is not rounding noise
+        finally:
+            m.close()
+
+
+def test_coupled_main_loop_full_size_vs_reference_sample():
+    """BASELINE configs[3] at FULL size through qgcm_hip_coupled_steps: NAtl 5 km ocean (961 x 961 x 3) and the
+    385 x 97 x 3 atmosphere on this GPU, forcing held, against samples of the coupled reference build itself after
+    nt = 9 (three ocean steps) and nt = 30 (ten) - tests/golden/make_golden_atmos.py coupled_fullsize."""
+    from common import cpl_fullsize_errs, cpl_fullsize_inputs
+    from qgcm_hip import AtmosModel, OceanModel, coupled_steps
+    g = load_golden("cpl_natl5_sample")
+    oc, at = config.preset("cpl_natl5"), config.atmos_preset("cpl_natl5")
+    po, pom, wekpo, f = cpl_fullsize_inputs(g, oc, at)
+    o = OceanModel(oc)
+    a = AtmosModel(at, ddynat=f["ddynat"])
+    o.set_p(po, pom)
+    o.set_forcing(wekpo, np.zeros_like(wekpo), np.zeros(oc.nlo - 1))
+    atm_apply(a, f)
+    done = 0
+    for upto, tol in ((9, 1e-12), (30, 1e-11)):
+        coupled_steps(o, a, done + 1, upto - done, int(g["nstr"]))
+        done = upto
+        e = cpl_fullsize_errs(o, a, g, upto)
+        assert all(v < tol for v in e.values()), (upto, e)
+    o.close()
+    a.close()
+
+
 def test_atmosphere_entry_points_reject_an_ocean_handle():
     from qgcm_hip import OceanModel, QgcmHipError, check
     m = OceanModel(config.preset("cyc_tiny"))

@@ -40,6 +40,8 @@ def test_native_library_is_loaded():
 
 def test_helmholtz_vs_reference(case):
     cfg, g, m = case
+    if "helm_rhs" not in g:
+        pytest.skip("the *_ah2 fixtures carry no Helmholtz vectors (the solver does not see ah2oc)")
     assert relerr(m.helmholtz(g["helm_rhs"], g["helm_boc"]), g["helm_sol"]) < TOL_CALL
     assert relerr(m.helmholtz(g["helm_rhs"], g["helm_boc0"]), g["helm_sol0"]) < TOL_CALL
 
@@ -418,6 +420,61 @@ def test_long_row_transform_sizes(nxto, cyclic):
     finally:
         m.close()
         o.close()
+
+
+@pytest.mark.parametrize("nxto,cyclic", [(960, False), (4800, False), (192, True), (384, True), (960, True), (4608, True),
+                                         (4800, True), (96, True), (48, False)])
+def test_row_transforms_against_fftpack_vectors(nxto, cyclic):
+    """The device row transforms BY THEMSELVES (qgcm_hip_wrk_set / qgcm_hip_row_transform / qgcm_hip_wrk_get) against
+    known answers of FFTPACK itself (tests/golden/fftpack_eigmod.npz, fftpack_long.npz: dsint at n = nxto - 1, drfftf /
+    drfftb at n = nxto, generated from the reference build): every kernel family - wave-per-row-pair (960 = 64*15,
+    192, 384), three-stage register radix (4608, 4800), generic Stockham (96, 48) - forward (unnormalised, the cyclic
+    spectrum in FFTPACK's half-complex order) and inverse.  SURVEY 7 step 5."""
+    from qgcm_hip import OceanModel
+    from qgcm_hip.config import OceanConfig
+    g = {**load_golden("fftpack_eigmod"), **load_golden("fftpack_long")}
+    TOLF = 5e-14  # two factorisations of one transform, relative to the row's largest coefficient (CPU oracle: 1.6e-14 at 4800)
+    base = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True) if cyclic else dict(fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
+    nd = 8 if nxto % 8 == 0 and nxto >= 64 else 4
+    nxa = nxto // nd
+    cfg = OceanConfig("rows_%d" % nxto, nxa if cyclic else nxa + 2, 6, nxa, 2, nd, 3, dxo=5.0e3, **base)
+    assert cfg.nxto == nxto
+    nx, ny, nl = cfg.nxpo, cfg.nypo, cfg.nlo
+    m = OceanModel(cfg)
+    try:
+        rng = np.random.default_rng(nxto)
+        w = np.asfortranarray(rng.standard_normal((nx, ny, nl)))
+        if cyclic:
+            x, f, b = g["drfft_in_%d" % nxto], g["drfftf_out_%d" % nxto], g["drfftb_out_%d" % nxto]
+            cols = slice(0, nxto)
+        else:
+            x = g["dsint_in_%d" % (nxto - 1)]
+            f = g["dsint_out_%d" % (nxto - 1)]
+            cols = slice(1, nxto)
+        # the known vector in an even and an odd position of a row pair, in two modes; random rows elsewhere
+        where = [(1, 0), (2, 0), (ny - 2, 2), (4, 1)]
+        for j, mm in where:
+            w[cols, j, mm] = x
+        m.wrk_set(w)
+        m.row_transform(0)
+        got = m.wrk_get()
+        for j, mm in where:
+            assert relerr(got[cols, j, mm], f) < TOLF, ("forward", j, mm)
+        if cyclic:  # inverse of FFTPACK's own spectrum: drfftb
+            for j, mm in where:
+                w[cols, j, mm] = f
+            m.wrk_set(w)
+            m.row_transform(1)
+            got = m.wrk_get()
+            for j, mm in where:
+                assert relerr(got[cols, j, mm], b) < TOLF, ("inverse", j, mm)
+        else:       # dsint is its own inverse up to 2 (n + 1)  (src/fftpack/newbihar/fft.doc:342-344)
+            m.row_transform(1)
+            back = m.wrk_get()
+            for j, mm in where:
+                assert relerr(back[cols, j, mm] / (2.0 * nxto), x) < TOLF, ("inverse", j, mm)
+    finally:
+        m.close()
 
 
 @pytest.mark.parametrize("nyaooc,nranks", [(100, 1), (160, 1), (200, 2)])
@@ -951,6 +1008,47 @@ def test_full_size_natl1_slabs_vs_oracle():
         o.close()
 
 
+def test_natl5_long_run_within_the_references_own_thread_spread():
+    """SURVEY 8(d)'s long-run tolerances at BASELINE's full size (NAtl 5 km, 961 x 961 x 3, configs[1]): after 160
+    ocean steps <= 1e-9, after 1600 (ten model days) <= 1e-7 of the field's max-norm, against samples of the REFERENCE
+    ITSELF (tests/golden/natl5_long_sample.npz, make_golden_longrun.py: 8 OpenMP threads).  The fixture also holds the
+    reference's own 8- vs 1-thread difference over the full fields (its OpenMP sums depend on the thread count): the
+    yardstick SURVEY prescribes - the device must not be further from the reference than ten times that, or the
+    tolerance, whichever is larger."""
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("natl5")
+    g = load_golden("natl5_long_sample")
+    st = int(g["stride"])
+    po = synth.gaussian_eddy(cfg, noise=1e-3)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    assert np.array_equal(po[::st, ::st], g["in_po"]) and np.array_equal(wek[::st, ::st], g["in_wekpo"])
+    m = OceanModel(cfg)
+    try:
+        m.set_p(po, po)
+        m.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+        done, log = 0, []
+        for s, tol in ((160, 1e-9), (1600, 1e-7)):
+            m.steps(s - done, s0=done + 1)
+            done = s
+            for i, n in enumerate(FIELDS):
+                err = float(np.abs(m.get_state()[i][::st, ::st] - g["steps%d_%s" % (s, n)]).max() / float(g["steps%d_%s_max" % (s, n)]))
+                spread = float(g["spread%d_%s" % (s, n)])
+                log.append("step %d %s: device vs reference %.2e, reference 8 vs 1 threads %.2e" % (s, n, err, spread))
+                assert err < max(tol, 10.0 * spread), log[-1]
+            sr, s1, sm = g["steps%d_scal" % s], g["steps%d_scal_1thread" % s], m.get_scalars()
+            scale = cfg.xlo * cfg.ylo * float(g["steps%d_po_max" % s])
+            n1 = 2 * (cfg.nlo - 1)
+            assert np.abs(sm[:n1] - sr[:n1]).max() / scale < max(tol, 10.0 * np.abs(s1[:n1] - sr[:n1]).max() / scale)
+        try:
+            with open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "natl5_long_run_errors.log"), "w") as f:
+                f.write("\n".join(log) + "\n")
+        except OSError:
+            pass
+    finally:
+        m.close()
+
+
 def test_cyclic_continuity_monitors_vs_reference():
     """ermaso / emfroc of the zonally cyclic ocinvq (MODULE monitor, src/ocisubs.F:268-283; round 2 skipped them): the
     device values after each of six steps against the TRUE reference (tests/golden/cyc_tiny_monitors.npz,
@@ -987,6 +1085,44 @@ def test_cyclic_continuity_monitors_vs_reference():
                 assert np.abs(g["step%d_emfroc" % s]).min() > 1e-5   # the fixture is not rounding noise
         finally:
             m.close()
+
+
+def test_cyclic_continuity_monitors_on_two_y_slabs():
+    """The same monitors on the y-slab path (two virtual ranks, the constraint algebra runs redundantly on every rank from
+    the gathered step messages): every rank's ermaso / emfroc after each of six steps against the reference fixture."""
+    import importlib.util
+    import torch
+    from qgcm_hip import hostinit
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    spec = importlib.util.spec_from_file_location("make_golden_monitors", os.path.join(GOLDEN, "make_golden_monitors.py"))
+    gm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gm)
+    g = load_golden("cyc_tiny_monitors")
+    cfg = preset("cyc_tiny")
+    po, wek, txis, txin = gm.inputs(cfg)
+    pom = np.asfortranarray(0.98 * po)
+    consts = global_consts(cfg)
+    qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+    qom = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], pom)
+    scal = hostinit.constr(cfg, consts["amatoc"], po, pom)
+    nranks = 2
+    slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, sync_each_call=True) for r, (g0, g1) in enumerate(partition(cfg.nypo, nranks))]
+    try:
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.scatter_state(po, pom, qo, qom, wek, np.zeros_like(wek), np.array(gm.XON), scal)
+        for sl in slabs:
+            sl.set_cyc_forcing(txis, txin, np.array(gm.ENIS), np.array(gm.ENIN))
+        for s in range(1, gm.NSTEPS + 1):
+            so.steps(1, s0=s)
+            sr = g["step%d_scal" % s]
+            scale = np.abs(sr[:cfg.nlo - 1]) + np.abs(sr[cfg.nlo - 1:2 * (cfg.nlo - 1)])
+            for sl in slabs:
+                e, f = sl.get_monitors()
+                assert (np.abs(e - g["step%d_ermaso" % s]) / scale).max() < 1e-12, (s, e, g["step%d_ermaso" % s])
+                assert np.abs(f - g["step%d_emfroc" % s]).max() < 1e-11, (s, f, g["step%d_emfroc" % s])
+    finally:
+        for sl in slabs:
+            sl.close()
 
 
 def test_full_size_natl1_eight_slabs_vs_reference_sample():
