@@ -171,15 +171,19 @@ contains
 #endif
 
 #ifdef sponge_layer_k247
-    ! src/q-gcm.F:1154-1168 (option nospl_in_ewbdy_k247 not defined): a Gaussian ramp in the distance to the
-    ! nearer zonal boundary plus one in the distance to the nearer meridional boundary
+    ! src/q-gcm.F:1154-1168: a Gaussian ramp in the distance to the nearer zonal boundary plus - unless the option
+    ! nospl_in_ewbdy_k247 ("N-S boundary only", what a periodic channel needs) is defined - one in the distance to the
+    ! nearer meridional boundary
     do j = 1, nypo
       do i = 1, nxpo
         r_spl(i,j) = 0.0d0 &
                    + exp( -2.0d0 * PI_ * ( ( 0.5d0 * dyo * dble(nypo) &
-                     - abs( dyo * dble(j) - 0.5d0 * dyo * dble(nypo) ) ) / ( l_spl ) )**2.0d0 ) &
+                     - abs( dyo * dble(j) - 0.5d0 * dyo * dble(nypo) ) ) / ( l_spl ) )**2.0d0 )
+#ifndef nospl_in_ewbdy_k247
+        r_spl(i,j) = r_spl(i,j) &
                    + exp( -2.0d0 * PI_ * ( ( 0.5d0 * dxo * dble(nxpo) &
                      - abs( dxo * dble(i) - 0.5d0 * dxo * dble(nxpo) ) ) / ( l_spl ) )**2.0d0 )
+#endif
       enddo
     enddo
 #endif

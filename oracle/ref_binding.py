@@ -30,7 +30,10 @@ CONFIGS = {
     # the tiny grids compiled with the fork's sponge layer (-Dsponge_layer_k247: src/qgosubs.F:203-205, ramp
     # src/q-gcm.F:1154-1168, constants src/parameters_data.F:140-144)
     "box_tiny_spl": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsponge_layer_k247"),
-    "cyc_tiny_spl": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1, "-Dsponge_layer_k247"),
+    # (the channel with nospl_in_ewbdy_k247, "N-S boundary only": the full ramp is not periodic in x - its values at
+    #  i = 1 and i = nxpo differ - and the reference, which steps the duplicate column nxpo by itself, would leave
+    #  qo(nxpo,j) != qo(1,j))
+    "cyc_tiny_spl": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1, "-Dsponge_layer_k247 -Dnospl_in_ewbdy_k247"),
     "cyc_tiny": (4, 8, "nxta", 3, 12, 3, "-1.19467D-04", "1.31301D-11", 1),
     "cyc_small": (6, 10, "nxta", 4, 16, 3, "-1.19467D-04", "1.31301D-11", 1),
     "box_natl5": (384, 96, 60, 60, 16, 3, "9.37456D-05", "1.75360D-11", 0),

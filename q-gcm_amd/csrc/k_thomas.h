@@ -72,7 +72,7 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 }
 
 // PHASE 0  whole column in this handle: zero inflow at both ends, 1 read + 1 write.
-// y-slab decomposition (one exchange per step):
+// y-slab decomposition (one exchange per step, ONE pass over the work array):
 //   u = u0 + uin*P,  v = B(u) + vin*Q  are linear in the values uin / vin that enter
 //   the slab from the ranks below / above, so a slab is summarised by
 //     Cf  = last value of the zero-inflow forward sweep,
@@ -89,11 +89,18 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // linear in the inflows too:  sum_j v_j = S0 + uin*SP + vin*SQ  (S0: zero-inflow sum, SP / SQ:
 // sums of the unit responses, right-hand-side independent), so every rank forms the basin-wide
 // ksum from the one all-gather of the slab summaries - bitwise the same on every rank.
-// PHASE 1  publish (Cf, Cb, S0) per wavenumber; nothing is written to wrk.
-// PHASE 2  compose all ranks' summaries into uin, vin and the basin-wide ksum (lanes = ranks,
-//          two affine scans), finish both sweeps, write.
-// PHASE 4  set-up: D, E and SP of this slab (input column = 0, unit inflow from below).
-// PHASE 5  set-up: SQ (input column = 0, unit inflow from above).
+// PHASE 1  the slab's ZERO-INFLOW solution, written in place (1 read + 1 write, the same work as
+//          PHASE 0), and (Cf, Cb, S0) per wavenumber published.  Rounds 1-3 published the summary
+//          WITHOUT writing and ran both sweeps again from the true inflows after the exchange (a
+//          second read + write of the whole array: NAtl 1 km 21 + 47 us per slab for one solve).
+//          Now what is left after the exchange is k_thomas_corr below: the full responses to the
+//          inflows, uin*Pv_r + vin*Qv_r, are ADDED to the rows they reach - they decay like
+//          lambda^distance from the slab's ends, so for all but the lowest wavenumbers that is a few
+//          rows (tables of Pv / Qv up to where they drop below 1e-19 of the inflow, built once at
+//          set-up from PHASE 4 / 5's own output, QgThomasParams.corr*).
+// PHASE 4  set-up: D, E and SP of this slab (input column = 0, unit inflow from below); the
+//          response Pv is left in the work array for the table build.
+// PHASE 5  set-up: SQ (input column = 0, unit inflow from above); Qv left in the work array.
 // per-step message of one rank: TH_MSG doubles (Cf, Cb, S0) at TH_MSG*(m*ldw + k); the right-hand-side independent
 // part (D, E, SP, SQ: TH_CST doubles, the layout of slabDE) is exchanged ONCE after set-up (cgath)
 // grid: (ceil(nk/16), nlayers)
@@ -106,10 +113,8 @@ __device__ __forceinline__ void affine_scan(double &Cs, double &Ds, int lane) {
 // 16 rows per thread; 8 (512 threads, 256 VGPRs) for the long columns - R >= 20 keeps 4R doubles of rows and pivots in
 // registers and spilled 100-800 B per lane under the 128-VGPR limit.
 template <int R, int PHASE, bool CYCA = false, int KW = TH_KW>
-// (second launch bound = waves per SIMD.  The summary phase of a y-slab neither stores rows nor keeps them for the
-// backward sweep: with <= 10 rows per thread it fits 64 VGPRs, two workgroups share a CU and the launches of many
-// generations - NAtl 1 km: 900 workgroups - gain a quarter: 29 -> 21 us.  PHASE 2 at 64 VGPRs spills: 50 -> 70 us.)
-__global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8 : ((KW == 8 && R <= 16) ? 4 : 1)) void k_thomas(const QgThomasParams P) {
+// (second launch bound = waves per SIMD: 512-thread workgroups of 8 wavenumbers share a CU in pairs at 128 VGPRs)
+__global__ __launch_bounds__(KW * TH_NC, (KW == 8 && R <= 16) ? 4 : 1) void k_thomas(const QgThomasParams P) {
   static_assert(TH_KW % KW == 0, "a workgroup's wavenumbers lie inside one block of the pivot tables");
   static_assert(KW % 2 == 0, "the write-through stores pair the lanes of neighbouring wavenumbers");
   // pitch TH_KW + 1: the scans read / write these arrays transposed ([lane][wv]: 64 lanes at a stride of one row);
@@ -194,44 +199,9 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
         if (r0 + t >= nr) b[t] = 0.0;
     }
   }
-  // values entering the slab from the other ranks
-  double uin = (PHASE == 4) ? 1.0 : 0.0, vin = (PHASE == 5) ? 1.0 : 0.0;
-  if (PHASE == 2) {
-    // lane s stands for rank s (at most 64 slabs); wave wv works on wavenumber kq
-    const bool act = lane < P.nranks && kq < P.g.nk;
-    const double *gs = P.gath + (long)lane * P.gath_stride + mk;                              // this step's summaries
-    const double *gc = P.cgath + (long)lane * (TH_CST * P.g.nl * ldw) + TH_CST * ((long)m * ldw + kq); // set-up constants
-    const double gCf = act ? gs[0] : 0.0, gCb = act ? gs[1] : 0.0, gS0 = act ? gs[2] : 0.0;
-    const double gD = act ? gc[0] : 1.0, gE = act ? gc[1] : 0.0, gSP = act ? gc[2] : 0.0, gSQ = act ? gc[3] : 0.0;
-    // forward chain: value leaving rank s = Cf_s + D_s * (value entering rank s), nothing enters rank 0
-    double Cs = gCf, Ds = gD;
-    affine_scan(Cs, Ds, lane);
-    double up = __shfl_up(Cs, 1);
-    const double uin_s = (lane == 0) ? 0.0 : up;
-    // backward chain, last rank first: value leaving rank s downwards = Cb_s + E_s*uin_s + D_s * (value entering from above)
-    const int rr = 63 - lane;
-    double C2 = __shfl(gCb + gE * uin_s, rr), D2 = __shfl(gD, rr);
-    affine_scan(C2, D2, lane);
-    double vp = __shfl_up(C2, 1);
-    const double vin_rr = (lane == 0) ? 0.0 : vp; // enters rank rr from above
-    const double vin_s = __shfl(vin_rr, rr);
-    double term = gS0 + uin_s * gSP + vin_s * gSQ; // column sum of rank s (0 for lanes past the last rank)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off);
-    uin = __shfl(uin_s, P.rank);
-    vin = __shfl(vin_s, P.rank);
-    if (lane == 0 && kq < P.g.nk) P.ksum[(long)m * ldw + kq] = ft * term;
-    if (P.ybnd && kq == 0) {
-      // cyclic constraints: the zonal-mean solution next to the two zonal boundaries, on every rank, from the
-      // summaries: the value leaving rank 0 downwards is the solution at its first row (global row 2); the forward
-      // value leaving the last rank is the solution at its last row (global row nyg-1: nothing enters from above)
-      const double vfirst = __shfl(C2, 63), vlast = __shfl(Cs, P.nranks - 1);
-      if (lane == 0) {
-        P.ybnd[2 * m] = ft * vfirst;
-        P.ybnd[2 * m + 1] = ft * vlast;
-      }
-    }
-  }
+  // values entering the slab: none (the inflows of the other ranks are added by k_thomas_corr), or the unit inflows
+  // of the set-up phases
+  const double uin = (PHASE == 4) ? 1.0 : 0.0, vin = (PHASE == 5) ? 1.0 : 0.0;
   // ---- forward: local affine maps (zero inflow); rows past the slab are the identity (PRED) or the zero map (PHASE 0)
   double C = 0.0, D = 1.0;
 #pragma unroll
@@ -308,7 +278,7 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
     }
   }
   QG_STAMP(1, 6);
-  if (PHASE == 0 || PHASE == 2) {
+  {
     if (R % 2 == 0) {
       // 16-byte write-through stores (qgcm_dev.h: all of this kernel's stores come at its very end): the lanes of two
       // neighbouring wavenumbers swap one value per pair of rows, the even lane then stores row t for both, the odd
@@ -348,7 +318,6 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
       if (r0 + t == nr - 1) P.ybnd[2 * m + 1] = ft * w[t];
     }
   }
-  if (PHASE == 2) return; // the basin-wide column sums came from the summaries
   // column sum of this slab: chunks in a fixed order (lanes of wave wv = chunks of wavenumber kq)
   sC[c][kk] = colsum;
   __syncthreads();
@@ -370,4 +339,177 @@ __global__ __launch_bounds__(KW * TH_NC, (R <= 10 && PHASE == 1 && KW == 16) ? 8
   } else {
     cst[3] = tot;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// y-slabs, after the exchange of the slab summaries: k_thomas_corr.
+//   1. composes all ranks' summaries (lanes = ranks, two affine scans per wavenumber) into the values uin / vin that
+//      enter THIS slab from below / above, the basin-wide column sums ksum (bitwise the same on every rank) and, for
+//      the zonally cyclic oceans, the zonal-mean solution next to the two zonal boundaries (ybnd);
+//   2. adds the slab's full responses to those inflows to the zero-inflow solution PHASE 1 left in the work array:
+//          v_r += uin * Pv_r  (rows r < np of the block)  +  vin * Qv_r  (the last nq rows),
+//      Pv / Qv from the tables built at set-up.  Everything is scaled by ftnorm, as the stored rows are.
+// Workgroup = one block of TH_KW wavenumbers (a 128-byte line per row): 256 threads; in step 2 a thread owns a pair
+// of neighbouring wavenumbers (16-byte loads / stores) in every 32nd row.  grid: (ceil(nk/16), nlayers).
+// The rows are independent of one another here - no sweep, no scan, no divide: the pass is bound by the bytes it
+// touches, 2 x 8 B per corrected element + 8 B of table (NAtl 1 km, 600-row slabs: ~ 20 % of the rows on average).
+struct QgThomasCorr {
+  const double *ptab, *qtab; // responses, TH_KW doubles per row: block b of layer m starts at row poff / qoff of its table
+  const int *np, *nq;        // (nblk, nlayers) rows within reach of the lower / upper inflow (0: no neighbour on that side)
+  const int *poff, *qoff;
+};
+#define THC_NT 256
+#define THC_UNR 4 // rows in flight per thread and trip of the correction loop
+#define THC_PER ((TH_MSG + TH_CST) * TH_KW) // doubles per rank and block: summaries + constants of 16 wavenumbers
+#define THC_LDS (THC_PER + TH_KW + 1)       // ... + the inflow per wavenumber (+ 1: bank spread between ranks)
+__global__ __launch_bounds__(THC_NT) void k_thomas_corr(const QgThomasParams P, const QgThomasCorr T) {
+  // 256 threads: four workgroups share a CU (the pass is all memory latency).  Every thread first requests its first
+  // rows and table entries, then the workgroup fetches all ranks' summaries of the block's 16 wavenumbers into LDS in
+  // one round trip - the two latencies overlap instead of adding - and 16 lanes run the two short chains of
+  // multiply-adds over the ranks.  (Measured, NAtl 1 km, 600-row slabs: 1024-thread workgroups
+  // composing with one wave scan per wavenumber 20.8 us; 256 threads, four scans per wave one after the other: 24.5 us.)
+  __shared__ double sU[TH_KW], sV[TH_KW];
+  extern __shared__ double sG[]; // dynamic: nranks x (THC_PER doubles of summaries and constants + TH_KW inflows)
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x, m = blockIdx.y + P.layer0;
+  const int ldw = P.g.ldw;
+  const double ft = P.ftnorm;
+  const int tb = m * P.nblk + bx;
+  const int np = T.np[tb], nq = T.nq[tb];
+  const int nr = P.g.jr1 - P.g.jr0 + 1;
+  const int kp = tid & 7, c = tid >> 3; // pair of wavenumbers 2 kp, 2 kp + 1 of the block; rows c, c + 32, ...
+  constexpr int STEP = THC_NT / 8;
+  const bool pair_ok = bx * TH_KW + 2 * kp < P.g.nk; // (the second of a pair may be the row's padding column: ldw > nk)
+  double *wb = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * ldw + bx * TH_KW + 2 * kp;
+  const double *pt = T.ptab + (long)T.poff[tb] * TH_KW + 2 * kp;
+  const double *qt = T.qtab + (long)T.qoff[tb] * TH_KW + 2 * kp;
+  const int q0 = nr - nq; // first row the upper inflow reaches (table row r - q0)
+  // the rows to correct: [0, np) and [max(np, q0), nr), as one index space of n1 + n2 rows
+  const int n1 = np, s2 = np > q0 ? np : q0, ntot = n1 + (nr - s2);
+  double2 w[THC_UNR], a[THC_UNR], b[THC_UNR];
+  auto row_of = [&](int x) { return x < n1 ? x : s2 + (x - n1); };
+  auto request = [&](int x0) {
+#pragma unroll
+    for (int i = 0; i < THC_UNR; ++i) {
+      const int x = x0 + i * STEP;
+      const int r = row_of(x < ntot ? x : ntot - 1); // clamped: unconditional loads
+      w[i] = *reinterpret_cast<const double2 *>(wb + (long)r * ldw);
+      a[i] = double2{0.0, 0.0};
+      b[i] = double2{0.0, 0.0};
+      if (r < np) a[i] = *reinterpret_cast<const double2 *>(pt + (long)r * TH_KW);
+      if (r >= q0 && nq > 0) b[i] = *reinterpret_cast<const double2 *>(qt + (long)(r - q0) * TH_KW);
+    }
+  };
+  // blockIdx.z: slice of THC_UNR * STEP = 128 of those rows (one trip of the loop below per workgroup: the blocks of
+  // the lowest wavenumbers, whose responses reach through the whole slab, otherwise run 5 trips = 5 memory round trips
+  // one after the other while everybody else has long finished - measured 22.7 us per 600-row slab of NAtl 1 km)
+  const int xa = blockIdx.z * (THC_UNR * STEP), xb0 = xa + THC_UNR * STEP, xb = xb0 < ntot ? xb0 : ntot;
+  if (blockIdx.z > 0 && xa >= ntot) return; // (uniform; slice 0 always composes: it owns ksum / ybnd)
+  const bool work = xa < ntot && pair_ok;
+  if (work) request(xa + c);
+  // every rank's summaries (Cf, Cb, S0) and constants (D, E, SP, SQ) of the block's 16 wavenumbers: 48 + 64 contiguous
+  // doubles per rank, fetched by the whole workgroup in one round trip
+  {
+    const long mk0 = TH_MSG * ((long)m * ldw + bx * TH_KW), ck0 = TH_CST * ((long)m * ldw + bx * TH_KW);
+    const long cstride = (long)TH_CST * P.g.nl * ldw;
+    for (int it = tid; it < P.nranks * THC_PER; it += THC_NT) {
+      const int sr = it / THC_PER, jj = it - sr * THC_PER;
+      sG[sr * THC_LDS + jj] = jj < TH_MSG * TH_KW ? P.gath[(long)sr * P.gath_stride + mk0 + jj]
+                                                  : P.cgath[(long)sr * cstride + ck0 + (jj - TH_MSG * TH_KW)];
+    }
+  }
+  __syncthreads();
+  if (tid < TH_KW) {
+    // lane = wavenumber kq of the block; ranks s = 0 .. nranks-1 in turn (operands in LDS: two short chains)
+    const int kq = bx * TH_KW + tid;
+    const double *gk = sG + TH_MSG * tid, *ck = sG + TH_MSG * TH_KW + TH_CST * tid;
+    // forward chain: value leaving rank s = Cf_s + D_s * (value entering rank s), nothing enters rank 0
+    double u = 0.0, mine_u = 0.0, vlast = 0.0;
+    for (int sr = 0; sr < P.nranks; ++sr) {
+      sG[sr * THC_LDS + THC_PER + tid] = u;
+      if (sr == P.rank) mine_u = u;
+      u = __builtin_fma(ck[sr * THC_LDS], u, gk[sr * THC_LDS]);
+      vlast = u;
+    }
+    // backward chain, last rank first: value leaving rank s downwards = Cb_s + E_s*uin_s + D_s * (value entering from above)
+    double v = 0.0, mine_v = 0.0, term = 0.0, vfirst = 0.0;
+    for (int sr = P.nranks - 1; sr >= 0; --sr) {
+      const double *gs = gk + sr * THC_LDS, *gc = ck + sr * THC_LDS;
+      const double us = sG[sr * THC_LDS + THC_PER + tid];
+      if (sr == P.rank) mine_v = v;
+      term += gs[2] + us * gc[2] + v * gc[3]; // column sum of rank s: S0 + uin*SP + vin*SQ
+      v = __builtin_fma(gc[0], v, gs[1] + gc[1] * us);
+      vfirst = v;
+    }
+    sU[tid] = ft * mine_u;
+    sV[tid] = ft * mine_v;
+    if (kq < P.g.nk && blockIdx.z == 0) P.ksum[(long)m * ldw + kq] = ft * term;
+    if (P.ybnd && kq == 0 && blockIdx.z == 0) {
+      // cyclic constraints: the zonal-mean solution next to the two zonal boundaries, on every rank, from the
+      // summaries: the value leaving rank 0 downwards is the solution at its first row (global row 2); the forward
+      // value leaving the last rank is the solution at its last row (global row nyg-1: nothing enters from above)
+      P.ybnd[2 * m] = ft * vfirst;
+      P.ybnd[2 * m + 1] = ft * vlast;
+    }
+  }
+  if (xa >= ntot) return; // (uniform: no barrier is skipped by part of the workgroup)
+  __syncthreads();
+  if (!pair_ok) return;
+  const double u0 = sU[2 * kp], u1 = sU[2 * kp + 1], v0 = sV[2 * kp], v1 = sV[2 * kp + 1];
+  {
+    const int x0 = xa + c;
+#pragma unroll
+    for (int i = 0; i < THC_UNR; ++i) {
+      const int x = x0 + i * STEP;
+      if (x < xb) {
+        const double xx = __builtin_fma(v0, b[i].x, __builtin_fma(u0, a[i].x, w[i].x));
+        const double yy = __builtin_fma(v1, b[i].y, __builtin_fma(u1, a[i].y, w[i].y));
+        qg_store16_wt(wb + (long)row_of(x) * ldw, xx, yy);
+      }
+    }
+  }
+}
+
+// set-up of the tables: how far a unit inflow reaches into the slab.  The work array holds PHASE 4's (from_top = 0:
+// the response decays upwards from row 0) or PHASE 5's (from_top = 1: downwards from the last row) output, scaled by
+// ftnorm; per block of TH_KW wavenumbers the number of rows up to the last one with an entry above tol.
+// grid: (nblk, nlayers), 256 threads
+__global__ __launch_bounds__(256) void k_thomas_reach(const QgThomasParams P, int from_top, double tol, int *reach) {
+  __shared__ int smax[256];
+  const int tid = threadIdx.x, kk = tid % TH_KW, c = tid / TH_KW;
+  const int bx = blockIdx.x, m = blockIdx.y;
+  const int nr = P.g.jr1 - P.g.jr0 + 1;
+  const int k = bx * TH_KW + kk;
+  const double *wb = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * P.g.ldw + k;
+  int far = 0; // rows counted from the end the inflow enters at
+  if (k < P.g.nk)
+    for (int r = c; r < nr; r += 256 / TH_KW) {
+      const double v = wb[(long)r * P.g.ldw];
+      if (!(fabs(v) <= tol)) { // (a NaN counts as "reaches")
+        const int d = from_top ? nr - r : r + 1;
+        far = d > far ? d : far;
+      }
+    }
+  smax[tid] = far;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) smax[tid] = smax[tid] > smax[tid + s] ? smax[tid] : smax[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) reach[m * P.nblk + bx] = smax[0];
+}
+
+// ... and the copy of those rows into the packed table, divided by ftnorm (the stored rows carry it, the tables do
+// not: k_thomas_corr multiplies the inflows by it).  grid: (nblk, nlayers), 256 threads
+__global__ __launch_bounds__(256) void k_thomas_pack(const QgThomasParams P, int from_top, const int *reach, const int *off,
+                                                     double *tab) {
+  const int tid = threadIdx.x, kk = tid % TH_KW, c = tid / TH_KW;
+  const int bx = blockIdx.x, m = blockIdx.y;
+  const int nr = P.g.jr1 - P.g.jr0 + 1;
+  const int k = bx * TH_KW + kk;
+  const int n = reach[m * P.nblk + bx];
+  const int r0 = from_top ? nr - n : 0;
+  const double *wb = P.wrk + P.g.wstride * m + (long)(P.g.jr0 - 1) * P.g.ldw + k;
+  double *t = tab + (long)off[m * P.nblk + bx] * TH_KW + kk;
+  for (int r = c; r < n; r += 256 / TH_KW) t[(long)r * TH_KW] = (k < P.g.nk) ? wb[(long)(r0 + r) * P.g.ldw] / P.ftnorm : 0.0;
 }

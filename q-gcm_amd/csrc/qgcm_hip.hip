@@ -71,6 +71,12 @@ struct qgcm_hip_ctx {
   const double *oml_gath = nullptr;        // y-slabs: the gathered sums of the mixed layer's stage 10 (3, nranks)
   double *bpart_out = nullptr;             // where k_tend's extra workgroups put the boundary line sums (bpart, or the tail of the step message)
   QgThomasTab tt, tt_tmp;                  // Thomas pivot tables of the modal solves / of the last qgcm_hip_helmholtz
+  // y-slabs: the slab's responses to unit inflows from below / above, tabulated as far as they reach (k_thomas_corr)
+  struct {
+    double *ptab = nullptr, *qtab = nullptr;
+    int *meta = nullptr; // np, nq, poff, qoff: (nblk, nl) each
+    size_t prows = 0, qrows = 0;
+  } corr;
   double *slabDE;                          // y-slab summary constants (D, E, SP, SQ) per (mode, wavenumber)
   double *th_cgath = nullptr;              // all ranks' slabDE (rank-major), exchanged once (qgcm_hip_set_thomas_consts)
   int th_cgath_ranks = 0;
@@ -315,6 +321,9 @@ extern "C" int qgcm_hip_destroy(qgcm_hip_handle c) {
   hipFree(c->sc);
   if (c->d_cycq) hipFree(c->d_cycq);
   if (c->d_boxq) hipFree(c->d_boxq);
+  if (c->corr.ptab) hipFree(c->corr.ptab);
+  if (c->corr.qtab) hipFree(c->corr.qtab);
+  if (c->corr.meta) hipFree(c->corr.meta);
   for (QgThomasTab *t : {&c->tt, &c->tt_tmp}) {
     if (t->binf) hipFree(t->binf);
     if (t->ptab) hipFree(t->ptab);
@@ -417,6 +426,51 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
                          bool cyc_part_a = false);
 static void fill_cyc_constr_params(qgcm_hip_ctx *c, QgCycConstrParams &Q);
 
+static void fill_thomas_params(qgcm_hip_ctx *c, QgThomasParams &P, double *wrk, const QgThomasTab &tab, int nlayers, int layer0);
+
+// Set-up of the y-slab solve (k_thomas.h): PHASE 4 / 5 give the slab's gain and response sums (slabDE) and leave the
+// responses Pv / Qv to unit inflows in the work array; they are tabulated per block of TH_KW wavenumbers as far as
+// they reach (above 1e-19 of the inflow) - towards a side without a neighbour nothing ever enters: no table.
+static int build_slab_responses(qgcm_hip_ctx *c) {
+  const QgGeom &g = c->g;
+  const int nblk = (g.nk + TH_KW - 1) / TH_KW, nm = nblk * g.nl;
+  const bool nb_lo = g.joff + g.jlo > 1, nb_hi = g.joff + g.jhi < g.nyg;
+  if (!c->corr.meta) HIPCHECK(hipMalloc((void **)&c->corr.meta, sizeof(int) * 4 * nm));
+  std::vector<int> meta((size_t)4 * nm, 0);
+  QgThomasParams P;
+  fill_thomas_params(c, P, c->wrk, c->tt, g.nl, 0);
+  const double tol = 1.0e-19 * P.ftnorm; // three orders below the rounding of the inflow itself
+  for (int side = 0; side < 2; ++side) { // 0: inflow from below (PHASE 4, Pv), 1: from above (PHASE 5, Qv)
+    if (launch_thomas(c, c->wrk, c->tt, g.nl, 4 + side, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+    double *&tab = side ? c->corr.qtab : c->corr.ptab;
+    size_t &rows = side ? c->corr.qrows : c->corr.prows;
+    if (tab) HIPCHECK(hipFree(tab));
+    tab = nullptr;
+    rows = 0;
+    int *d_reach = c->corr.meta + side * nm, *d_off = c->corr.meta + (2 + side) * nm;
+    if (!(side ? nb_hi : nb_lo)) continue; // reach 0 everywhere
+    hipLaunchKernelGGL(k_thomas_reach, dim3(nblk, g.nl), dim3(256), 0, c->stream, P, side, tol, d_reach);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(meta.data() + side * nm, d_reach, sizeof(int) * nm, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    size_t off = 0;
+    for (int i = 0; i < nm; ++i) {
+      meta[(2 + side) * nm + i] = (int)off;
+      off += meta[side * nm + i];
+    }
+    rows = off;
+    HIPCHECK(hipMalloc((void **)&tab, sizeof(double) * TH_KW * (off ? off : 1)));
+    HIPCHECK(hipMemcpyAsync(d_off, meta.data() + (2 + side) * nm, sizeof(int) * nm, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_thomas_pack, dim3(nblk, g.nl), dim3(256), 0, c->stream, P, side, (const int *)d_reach, (const int *)d_off, tab);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+  }
+  // (the sides without a neighbour: zero reach, zero offsets)
+  HIPCHECK(hipMemcpyAsync(c->corr.meta, meta.data(), sizeof(int) * 4 * nm, hipMemcpyHostToDevice, c->stream));
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 extern "C" int qgcm_hip_set_geometry(qgcm_hip_handle c, const double *yporel, const double *ddynoc) {
   if (!c || !yporel) QG_FAIL("qgcm_hip_set_geometry: null argument");
   const QgGeom &g = c->g;
@@ -499,8 +553,7 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
   }
   c->grid_set = true;
   // slab summary constants (gain, backward image and column sums of the unit responses), once
-  if (launch_thomas(c, c->wrk, c->tt, g.nl, 4, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
-  if (launch_thomas(c, c->wrk, c->tt, g.nl, 5, nullptr, nullptr, 0, 1, 0, nullptr)) return 1;
+  if (build_slab_responses(c)) return 1;
   {
     // weights of the spectral area integral (k_thomas.h): sum_{i=1}^{n-1} 2 sin(k i pi/n) = 2 cot(k pi/2n), k odd
     std::vector<double> wc((size_t)g.ldw, 0.0);
@@ -643,6 +696,15 @@ extern "C" int qgcm_hip_set_sponge(qgcm_hip_handle c, const double *r_spl, doubl
     c->rspl = nullptr;
     c->c1_spl = 0.0;
     return 0;
+  }
+  if (g.cyc) {
+    // A periodic channel needs a ramp that is periodic in x (the fork's option nospl_in_ewbdy_k247: N / S boundaries
+    // only).  The reference steps the duplicate column nxpo by itself (src/qgosubs.F:181), so with the full ramp of
+    // src/q-gcm.F:1164-1166, whose values at i = 1 and i = nxpo differ, its qo(nxpo,j) drifts away from qo(1,j); on
+    // the device column nxpo IS column 1 - refuse instead of differing silently.
+    for (int j = 0; j < g.ny; ++j)
+      if (r_spl[(size_t)j * g.nx] != r_spl[(size_t)j * g.nx + g.nx - 1])
+        QG_FAIL("qgcm_hip_set_sponge: r_spl(1,%d) != r_spl(nxpo,%d) - a zonally cyclic ocean needs a ramp that is periodic in x (build with -Dnospl_in_ewbdy_k247)", j + 1, j + 1);
   }
   if (!c->rspl && dalloc(&c->rspl, (size_t)g.fstride)) return 1;
   c->c1_spl = c1_spl;
@@ -948,37 +1010,59 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   return 0;
 }
 
-static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, int nlayers, int phase,
-                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st,
-                         bool cyc_part_a) {
-  if (!st) st = c->stream;
+static void fill_thomas_params(qgcm_hip_ctx *c, QgThomasParams &P, double *wrk, const QgThomasTab &tab, int nlayers, int layer0) {
   const QgGeom &g = c->g;
-  QgThomasParams P;
   memset(&P, 0, sizeof(P));
   P.g = g;
-  P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
   P.gath_stride = (long)slab_msg_len_oml(c);
-  if (phase == 2 && g.cyc) {
-    P.ybnd = c->ybnd;
-    c->slab_gath = gath;
-    c->slab_nranks = nranks;
-  } else if (phase == 0) {
-    c->slab_gath = nullptr; // whole-column solve: the constraint algebra reads bpart
-    if (g.cyc && nlayers == g.nl) P.ybnd = c->ybnd; // ... and the zonal-mean rows next to the boundaries from here
-  }
   P.slabDE = c->slabDE;
-  P.cgath = (nranks == 1) ? c->slabDE : c->th_cgath; // a lone slab is its own rank 0
-  if (phase == 2 && nranks > 1 && (!c->th_cgath || c->th_cgath_ranks != nranks))
-    QG_FAIL("qgcm_hip_thomas_phase: the set-up constants of the %d slabs have not been exchanged (qgcm_hip_set_thomas_consts)", nranks);
   P.ksum = c->ksum;
   P.wrk = wrk;
-  if (!tab.binf) QG_FAIL("k_thomas: the pivot tables have not been built (qgcm_hip_set_grid)");
   P.binf = tab.binf; P.ptab = tab.ptab; P.rcb = tab.rcb; P.poff = tab.poff;
   P.nblk = (g.nk + TH_KW - 1) / TH_KW;
   P.aoc = c->prm.aoc;
   P.ftnorm = g.cyc ? 1.0 / g.nxt : 0.5 / g.nxt; // src/ocisubs.F:440, 547
   P.nlayers = nlayers;
   P.layer0 = layer0;
+  P.nranks = 1;
+}
+
+// phase 0: whole column; 1: the slab's zero-inflow solution + its summary (send); 2: after the exchange - the inflows
+// composed from all ranks' summaries (gath) and their responses added (k_thomas_corr); 4 / 5: set-up (k_thomas.h)
+static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, int nlayers, int phase,
+                         const double *gath, double *send, int rank, int nranks, int layer0, hipStream_t st,
+                         bool cyc_part_a) {
+  if (!st) st = c->stream;
+  const QgGeom &g = c->g;
+  if (!tab.binf) QG_FAIL("k_thomas: the pivot tables have not been built (qgcm_hip_set_grid)");
+  QgThomasParams P;
+  fill_thomas_params(c, P, wrk, tab, nlayers, layer0);
+  P.gath = gath; P.send = send; P.rank = rank; P.nranks = nranks;
+  if (phase == 2) {
+    if (g.cyc) P.ybnd = c->ybnd;
+    c->slab_gath = gath; // (the cyclic constraint algebra reads the boundary line sums at the end of the step messages)
+    c->slab_nranks = nranks;
+    P.cgath = (nranks == 1) ? c->slabDE : c->th_cgath; // a lone slab is its own rank 0
+    if (nranks > 1 && (!c->th_cgath || c->th_cgath_ranks != nranks))
+      QG_FAIL("qgcm_hip_thomas_phase: the set-up constants of the %d slabs have not been exchanged (qgcm_hip_set_thomas_consts)", nranks);
+    if (&tab != &c->tt || !c->corr.meta) QG_FAIL("k_thomas_corr: the response tables belong to the modal solves of qgcm_hip_set_grid");
+    const int nm = P.nblk * g.nl;
+    QgThomasCorr T;
+    T.ptab = c->corr.ptab; T.qtab = c->corr.qtab;
+    T.np = c->corr.meta; T.nq = c->corr.meta + nm; T.poff = c->corr.meta + 2 * nm; T.qoff = c->corr.meta + 3 * nm;
+    KTimer t(c, KN_THOMAS, st);
+    const size_t lds = sizeof(double) * THC_LDS * nranks;
+    if (lds > 32 * 1024) // (more than 31 slabs: beyond the default dynamic-LDS limit of a launch)
+      HIPCHECK(hipFuncSetAttribute((const void *)k_thomas_corr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nrows = g.jr1 - g.jr0 + 1, per = THC_UNR * (THC_NT / 8); // rows per slice (blockIdx.z)
+    hipLaunchKernelGGL(k_thomas_corr, dim3(P.nblk, nlayers, (nrows + per - 1) / per), dim3(THC_NT), lds, st, P, T);
+    HIPCHECK(hipGetLastError());
+    return 0;
+  }
+  if (phase == 0) {
+    c->slab_gath = nullptr; // whole-column solve: the constraint algebra reads bpart
+    if (g.cyc && nlayers == g.nl) P.ybnd = c->ybnd; // ... and the zonal-mean rows next to the boundaries from here
+  }
   // zonally cyclic geometries use the CYCA instantiation for the whole-column solve: it fills ybnd, and its extra
   // workgroup runs part A of the constraint algebra when asked to (inside qgcm_hip_steps)
   const bool cyca = (phase == 0 && g.cyc);
@@ -994,37 +1078,22 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
         else hipLaunchKernelGGL((k_thomas<RV, 0, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P);                      \
         break;                                                                                                           \
       case 1: hipLaunchKernelGGL((k_thomas<RV, 1, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;              \
-      case 2: hipLaunchKernelGGL((k_thomas<RV, 2, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;              \
       case 4: hipLaunchKernelGGL((k_thomas<RV, 4, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;              \
       default: hipLaunchKernelGGL((k_thomas<RV, 5, false, KWV>), gridk, dim3(KWV * TH_NC), 0, st, P); break;             \
     }                                                                                                                    \
   }
-  // 512-thread workgroups of 8 wavenumbers, two per CU (128 VGPRs), the pair that shares the 128-byte lines of a
-  // 16-wavenumber block on ONE XCD (k_thomas.h) - round 2 measured this shape slower, but with the pair's two halves
-  // of every line going through different L2s.  Measured with the pairing (r3): NAtl 5 km 10.6 -> 9.9 us (360
-  // workgroups spread over all 256 CUs instead of 180 on 180), SOcn 5 km 31.9 -> 30.8, NAtl 1 km slab sweep 50.0 ->
-  // 47.6.  QGCM_HIP_THOMAS_KW8=0 keeps the 1024-thread shape (A/B).
-  static const char *kw8env = getenv("QGCM_HIP_THOMAS_KW8");
-  const bool kw8 = kw8env ? kw8env[0] == '1' : true;
-  if (kw8 && (phase == 0 || phase == 2) && (c->thR == 8 || c->thR == 10 || c->thR == 12 || c->thR == 16)) {
-    switch (c->thR) {
-      case 8: QG_TH(8, 8); break;
-      case 10: QG_TH(10, 8); break;
-      case 12: QG_TH(12, 8); break;
-      default: QG_TH(16, 8); break;
-    }
-    HIPCHECK(hipGetLastError());
-    return 0;
-  }
+  // 8 .. 16 rows per thread: 512-thread workgroups of 8 wavenumbers, two per CU (128 VGPRs), the pair that shares the
+  // 128-byte lines of a 16-wavenumber block on ONE XCD (k_thomas.h; r3: NAtl 5 km 10.6 -> 9.9 us against 1024-thread
+  // workgroups); long columns (>= 20 rows per thread): 512 threads, 256 VGPRs; short ones: 1024 threads of 16 wavenumbers
   switch (c->thR) {
     case 1: QG_TH(1, 16); break;
     case 2: QG_TH(2, 16); break;
     case 4: QG_TH(4, 16); break;
-    case 8: QG_TH(8, 16); break;
-    case 10: QG_TH(10, 16); break;
-    case 12: QG_TH(12, 16); break;
-    case 16: QG_TH(16, 16); break;
-    case 20: QG_TH(20, 8); break; // long columns: 512-thread workgroups, 256 VGPRs (k_thomas.h)
+    case 8: QG_TH(8, 8); break;
+    case 10: QG_TH(10, 8); break;
+    case 12: QG_TH(12, 8); break;
+    case 16: QG_TH(16, 8); break;
+    case 20: QG_TH(20, 8); break;
     case 24: QG_TH(24, 8); break;
     case 32: QG_TH(32, 8); break;
     default: QG_FAIL("k_thomas: too many rows for the single-segment kernel");

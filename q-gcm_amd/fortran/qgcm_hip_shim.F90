@@ -19,7 +19,8 @@
 ! Build with the same cpp macros as the reference (-Docean_only ...).
 !-----------------------------------------------------------------------
 ! -Dsponge_layer_k247 (the fork's sponge term of the leapfrog step, src/qgosubs.F:70-72,175-205): the ramp r_spl
-! the main program sets (src/q-gcm.F:1154-1168) and c1_spl go to the device with the first push of the state.
+! and c1_spl go to the device at the first "call qgostep" - the main program sets r_spl late in its set-up
+! (src/q-gcm.F:1154-1168), after the point where the state is first pushed (after homsol, :976).
 module qgcm_hip_state
   use iso_c_binding
   use qgcm_hip_iface
@@ -27,6 +28,9 @@ module qgcm_hip_state
   private
   public :: qgcm_hip_handle, qgcm_hip_ensure, qgcm_hip_ensure_geometry, qgcm_hip_push, qgcm_hip_pull, &
             qgcm_hip_push_forcing, qgcm_hip_shutdown, qgcm_hip_homog_ready, qgcm_hip_device_owns
+#ifdef sponge_layer_k247
+  public :: push_sponge
+#endif
 
   type(c_ptr), save :: qgcm_hip_handle = c_null_ptr
   logical, save :: homog_sent = .false., grid_sent = .false.
@@ -118,9 +122,6 @@ contains
 #endif
     call qgcm_hip_check(qgcm_hip_set_scalars(qgcm_hip_handle, scal), 'qgcm_hip_set_scalars')
     call qgcm_hip_push_forcing
-#ifdef sponge_layer_k247
-    call push_sponge
-#endif
     qgcm_hip_device_owns = .true.
   end subroutine qgcm_hip_push
 
@@ -135,7 +136,7 @@ contains
 
 #ifdef sponge_layer_k247
   ! r_spl (MODULE occonst) is set late in the main program's set-up (src/q-gcm.F:1154-1168), before the time loop;
-  ! sent once - it does not change afterwards
+  ! sent once, by the first qgostep - it does not change afterwards
   subroutine push_sponge
     use parameters, only : c1_spl
     use occonst, only : r_spl
@@ -202,6 +203,9 @@ contains
   subroutine qgostep
     use qgcm_hip_iface
     use qgcm_hip_state
+#ifdef sponge_layer_k247
+    call push_sponge
+#endif
     call qgcm_hip_check(qgcm_hip_qgostep(qgcm_hip_handle), 'qgostep')
   end subroutine qgostep
 end module qgosubs

@@ -35,6 +35,7 @@ class OceanConfig:
     # l_spl = 0 means the option is not defined (every BASELINE configuration)
     c1_spl: float = 0.0
     l_spl: float = 0.0
+    spl_ns_only: bool = False  # cpp option nospl_in_ewbdy_k247: ramp at the zonal (N / S) boundaries only
 
     # derived grid parameters, src/parameters_data.F (nxto = ndxr*nxaooc, ...)
     @property
@@ -192,7 +193,7 @@ PRESETS = {
     "box_tiny_spl": OceanConfig("box_tiny_spl", 8, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
                                 ah4oc=(3.2e12,) * 3, c1_spl=-2.5e-5, l_spl=4.0e5, **_NATL),
     "cyc_tiny_spl": OceanConfig("cyc_tiny_spl", 4, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
-                                ah4oc=(3.2e12,) * 3, c1_spl=-2.5e-5, l_spl=4.0e5, **_SOCN),
+                                ah4oc=(3.2e12,) * 3, c1_spl=-2.5e-5, l_spl=4.0e5, spl_ns_only=True, **_SOCN),
     # nxto = 192 = 64*3: exercises the wave-per-row-pair DST kernel at a size the oracle runs in seconds
     "box_med": OceanConfig("box_med", 16, 10, 12, 6, 16, 3, dxo=2.5e4, dta=240.0,
                            ah4oc=(1.2e10,) * 3, **_NATL),

