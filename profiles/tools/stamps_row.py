@@ -5,7 +5,13 @@ sys.path.insert(0, "q-gcm_amd/python"); sys.path.insert(0, ".")
 import numpy as np
 from qgcm_hip import preset, synth
 from qgcm_hip.model import OceanModel
-cfg = preset(sys.argv[1] if len(sys.argv) > 1 else "socn5")
+name = sys.argv[1] if len(sys.argv) > 1 else "socn5"
+if name == "box4800":   # a box basin with the rows of NAtl 1 km (nxto = 4800) and the 600 rows of one of its eight slabs
+    from qgcm_hip.config import OceanConfig
+    cfg = OceanConfig("box4800", 602, 77, 600, 75, 8, 3, dxo=1.0e3, dta=60.0, bccooc=0.1, ah4oc=(5.0e7,) * 3,
+                      fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
+else:
+    cfg = preset(name)
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 slot = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 m = OceanModel(cfg, device=0)

@@ -206,8 +206,10 @@ __device__ __forceinline__ void dst_stage_generic(int R, const cplx *__restrict_
 template <int NL>
 __device__ __forceinline__ void constr_box_all(const QgConstrParams &P, int lane); // k_misc.h
 
+// (three-stage plans at 384 threads: 128 VGPRs, so that two workgroups of six waves fit a CU however their waves fall
+// on the four SIMDs - at 134-146 VGPRs the second workgroup did not become resident: FFT3_WPE)
 template <bool ROWSUM, int NT = DST_NT, class PLAN = FftPlanNatural>
-__global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
+__global__ __launch_bounds__(NT, (PLAN::three_stage && NT == 384) ? 4 : 1) void k_dst_box(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   if (P.boxq && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup of the inverse rows inside a step: the box constraint solve (one wave; nothing of it
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
   double *rowa = P.wrk + P.g.wstride * m + (long)(ja - 1) * ldw;
   double *rowb = rowa + ldw;
   typename PLAN::Tw tw3 = PLAN::template prefetch<NT>(P.twid, tid); // table values requested before the rows
+  QG_STAMP(0, 0);
 
   // ---- pre-twiddle (dsint.f:19-33): element a[k], k=1..n lives at index k-1
   const int ns2 = n / 2;
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     A[PLAN::pos_in(kc)] = {4.0 * xa, 4.0 * xb};
   }
   __syncthreads();
+  QG_STAMP(0, 1);
 
   // ---- complex FFT of length N, Stockham autosort ----------------------
   cplx *in = A, *out = B;
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     len = mm;
   }
   cplx *Z = single ? A : in;
+  QG_STAMP(0, 2);
 
   // ---- separate the two real spectra and post-process (dsint.f:37-44) ----
   //   Y_k  = (Z_k + conj Z_{N-k})/2      (row a)
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
     if (has_b) rsb += -imb;
   }
   __syncthreads();
+  QG_STAMP(0, 3);
   if (single) {
     // elements 2t, 2t+1 as one 16-byte write-through store (qgcm_dev.h; N is even here, and element n = N - 1 of the
     // last pair is the padding column of the row): b[2t] = Z[t].y (Z[0].x for t = 0), b[2t+1] = Z[t+1].x, row b alike
@@ -393,6 +399,9 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
       if (has_b) rowb[i] = ob[i];
     }
   }
+  QG_STAMP(0, 4);
+  QG_STAMP_DRAIN();
+  QG_STAMP(0, 5);
   if (ROWSUM) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(NT) void k_dst_box(const QgDstParams P) {
 __device__ __forceinline__ void rfft_cyc_constr_partB(const struct QgCycConstrParams *Q, int lane);
 
 template <bool INV, class PLAN = FftPlanNatural, int NT = RFFT_NT>
-__global__ __launch_bounds__(NT) void k_rfft_cyc(const QgDstParams P) {
+__global__ __launch_bounds__(NT, (PLAN::three_stage && NT == 384) ? 4 : 1) void k_rfft_cyc(const QgDstParams P) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   if (INV && P.cycq && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup of the inverse launch inside qgcm_hip_steps: c1, c2, c3 and the dpioc step from the

@@ -159,7 +159,7 @@ struct Fft3Plan {
   };
   template <int NT>
   static __device__ __forceinline__ Tw prefetch(const double2 *__restrict__ twid, int tid) {
-    static_assert(NT == 256, "four waves");
+    static_assert(NT % 64 == 0 && NT >= 256, "whole waves; the extra butterflies go to waves 1 .. 3");
     static_assert(R2 * R3 <= NT + 64 && R1 * R3 <= NT + 64 && R1 * R2 <= NT + 64, "at most one extra butterfly per lane");
     Tw t;
     const int e1 = extra_item<NT>(tid, 1, R2 * R3), e2 = extra_item<NT>(tid, 2, R1 * R3);

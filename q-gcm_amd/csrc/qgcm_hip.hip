@@ -17,7 +17,9 @@
 #include "k_dst.h"
 #include "k_fft3.h"
 // the row lengths with a three-stage plan: NAtl 1 km (4800), SOcn 5 km (4608), and two more for the tests
+#ifndef FFT3_NT
 #define FFT3_NT 256
+#endif
 #define QG_FFT3_PLANS(X) X(1, 15, 16, 20) X(2, 16, 16, 18) X(3, 16, 16, 16) X(4, 12, 15, 16)
 #include "k_dst64.h"
 #include "k_thomas.h"
