@@ -245,6 +245,10 @@ int qgcm_hip_area_integrals(qgcm_hip_handle h, double *xin);
  *            part of the tendency launch that reads no halo row (all but the first and last 16-row tile row; it may
  *            run before stage 3 of the previous step), stage 5 the rest of stage 1 (a = summary send buffer).  Needs
  *            at least three tile rows per slab and the mixed layer off.
+ *   stage 6 + stage 7 = stage 5 in two parts: stage 6 the outer tile rows + edge work of the tendency launch alone (it
+ *            may run on another stream BESIDE stage 4 - disjoint tiles - as soon as the halo rows are in: what
+ *            qgcm_hip_slab_steps does on the exchange's stream), stage 7 the forward rows and the summary sweep (after
+ *            stages 4 and 6; a = summary send buffer in both).
  * With the ocean mixed layer on the device (qgcm_hip_oml_init on every slab, before the buffers are sized) `call oml`
  * (src/q-gcm.F:1232) runs before stage 1, in two halves around ONE more all-gather of qgcm_hip_oml_msg_len() doubles
  * per rank (the mean entrainment is a basin-wide number, src/omlsubs.F:153):
@@ -276,8 +280,8 @@ int qgcm_hip_slab_steps(qgcm_hip_handle h, int s0, int n);
  * every rank must make the same choice */
 int qgcm_hip_comm_set_halo_p2p(qgcm_hip_handle h, int on);
 /* on = 1: the halo exchange of step s (and the halo unpack) run on a second stream while the handle's stream already
- * computes the tile rows of step s+1's tendency launch that need no halo row (stage 4), then waits and finishes
- * (stage 5).  Bitwise the same results.  Steps followed by a leapfrog averaging, the mixed layer and slabs of fewer
+ * computes the tile rows of step s+1's tendency launch that need no halo row (stage 4); the outer tile rows follow
+ * the halo rows on that second stream (stage 6), the handle's stream waits for them and goes on (stage 7).  Bitwise the same results.  Steps followed by a leapfrog averaging, the mixed layer and slabs of fewer
  * than three 16-row tile rows keep the plain order.  Collective choice, like the one above. */
 int qgcm_hip_comm_set_overlap(qgcm_hip_handle h, int on);
 /* measurement aid (collective): the step's exchanges back to back, microseconds each:

@@ -5,6 +5,9 @@
   natl1_one_slab                       the same set-up, then ONE middle slab stepped alone: its fields stay in the
                                        Infinity Cache between its kernels, as on its own GPU of eight (exchange buffers
                                        held at the last real step's values; no collective is timed)
+  natl5_one_slab_of_8 / _of_4 / _of_2  the headline basin (961 x 961 x 3) cut into 8 / 4 / 2 slabs, one middle slab stepped
+                                       alone the same way: what one GPU of an N-GPU run of BASELINE's metric computes per
+                                       step (the two exchanges not included)
 Eager launches (no graphs) so that every kernel shows in the trace with its own name."""
 import os
 import sys
@@ -27,11 +30,11 @@ if what == "atmos":
     for s in range(1201, 1201 + nsteps):   # eager, named kernels
         a.qgastep(); a.atinvq(); a.atqzbd()
     a.sync()
-elif what in ("natl1_slabs", "natl1_one_slab"):
+elif what in ("natl1_slabs", "natl1_one_slab", "natl5_slabs", "natl5_one_slab_of_8", "natl5_one_slab_of_4", "natl5_one_slab_of_2"):
     import torch
     from qgcm_hip import hostinit, preset, synth
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
-    cfg, P = preset("natl1"), 8
+    cfg, P = preset(what[:5]), (int(what.rsplit("_", 1)[1]) if "_of_" in what else 8)
     consts = global_consts(cfg)
     po = synth.gaussian_eddy(cfg)
     tx, ty = synth.wind_stress(cfg)
@@ -43,7 +46,7 @@ elif what in ("natl1_slabs", "natl1_one_slab"):
     so = SlabOcean(cfg, slabs, LocalComm(P, after=torch.cuda.synchronize))
     so.homsol()
     so.scatter_state(po, po, qo, qo, wek, z2, np.zeros(cfg.nlo - 1), scal)
-    if what == "natl1_slabs":
+    if what.endswith("_slabs"):
         so.steps(min(nsteps, 45), s0=1)
     else:
         import time
@@ -74,8 +77,30 @@ elif what in ("natl1_slabs", "natl1_one_slab"):
             t0 = time.perf_counter()
             one(per)
             tot += time.perf_counter() - t0
-        print("NAtl 1 km, slab %d of %d (rows %d..%d) alone: %.1f us per step over %d x %d steps (wall clock, launches queued ahead); slab finite: %s"
-              % (r, P, x.g0, x.g1, 1e6 * tot / (nch * per), nch, per, all(np.isfinite(f).all() for f in x.get_state())))
+        print("%s, slab %d of %d (rows %d..%d) alone: %.1f us per step over %d x %d steps (wall clock, launches queued ahead); slab finite: %s"
+              % (cfg.name, r, P, x.g0, x.g1, 1e6 * tot / (nch * per), nch, per, all(np.isfinite(f).all() for f in x.get_state())))
+        # the same four steps as ONE captured graph (no host in the loop: what qgcm_hip_slab_steps' graph mode replays,
+        # minus the two collectives), HIP events around each replay
+        try:
+            x.set_state(*state0); x.set_scalars(scal0)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                for _ in range(4):
+                    x.stage(1, so.th_send[r])
+                    mine.copy_(so.th_send[r])
+                    x.stage(2, so.th_gath[r], so.h_to_lo[r], so.h_to_hi[r])
+                    x.stage(3, so.h_from_lo[r], so.h_from_hi[r], None, 0)
+            e0, e1, tg = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 0.0
+            for _ in range(nch):
+                x.set_state(*state0); x.set_scalars(scal0)
+                with torch.cuda.stream(st):
+                    e0.record(); gr.replay(); e1.record()
+                e1.synchronize()
+                tg += e0.elapsed_time(e1)
+            print("%s, slab %d of %d alone, four steps as one captured graph: %.1f us per step (HIP events, %d replays)"
+                  % (cfg.name, r, P, 1e3 * tg / (4 * nch), nch))
+        except Exception as e:  # noqa: BLE001 - the eager figure above stands
+            print("graph replay of the slab stages not available: %r" % (e,))
     torch.cuda.synchronize()
     print("finite", all(np.isfinite(f).all() for _, _, fs in so.gather_local() for f in fs))
 else:

@@ -2258,22 +2258,24 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
   switch (stage) {
     case 1:
     case 4:   // the part of stage 1 that needs no halo row: the inner tile rows of the tendency launch
-    case 5: { // the rest of stage 1: outer tile rows + edge work, forward rows, summary sweep
+    case 5:   // the rest of stage 1: outer tile rows + edge work, forward rows, summary sweep
+    case 6:   // ... its first half alone: the outer tile rows + edge work of the tendency launch
+    case 7: { // ... and its second half: forward rows, summary sweep (after stages 4 AND 6)
       if (stage != 4 && !a) QG_FAIL("qgcm_hip_slab_stage: stage %d needs the send buffer", stage);
       if (check_ready(c, "qgcm_hip_slab_stage")) return 1;
       if (stage != 1 && (c->oml.on || !tend_can_split(c)))
-        QG_FAIL("qgcm_hip_slab_stage: stages 4 / 5 need a slab of at least three tile rows (%d rows each) and the mixed layer off", TEND_TY);
+        QG_FAIL("qgcm_hip_slab_stage: stages 4 - 7 need a slab of at least three tile rows (%d rows each) and the mixed layer off", TEND_TY);
       // cyclic: the boundary line sums of the tendency launch go straight into the tail of the step message
-      if (c->g.cyc && stage != 4) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
+      if (c->g.cyc && stage != 4 && stage != 7) c->bpart_out = a + (size_t)TH_MSG * c->g.nl * c->g.ldw;
       // box fast path: as in qgcm_hip_steps the leapfrog of dpioc is done by the tendency launch and the constraint
       // solve by the extra wave of the fused inverse-transform kernel of stage 2 (no k_constr_box launch)
       if (!c->homog_set) QG_FAIL("qgcm_hip_slab_stage: homogeneous solutions not set");
       // (with the mixed layer on, xon(1) is only complete after the all-gather: dpioc is stepped in stage 2 then)
       const bool fused_constr = can_fuse_dst_unpack(c) && !c->no_fused_constr && !c->oml.on; // can_fuse: box ocean only
-      const int rc = launch_tend(c, fused_constr, false, stage == 1 ? TEND_ALL : stage == 4 ? TEND_INNER : TEND_OUTER);
+      const int rc = stage == 7 ? 0 : launch_tend(c, fused_constr, false, stage == 1 ? TEND_ALL : stage == 4 ? TEND_INNER : TEND_OUTER);
       c->bpart_out = nullptr;
       if (rc) return 1;
-      if (stage == 4) return 0;
+      if (stage == 4 || stage == 6) return 0;
       c->iq ^= 1; // as qgcm_hip_qgostep
       if (qgcm_hip_row_transform(c, 0)) return 1;
       if (qgcm_hip_thomas_phase(c, 1, nullptr, a, rank, nranks)) return 1;
@@ -2335,7 +2337,7 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
       if (!a) QG_FAIL("qgcm_hip_slab_stage: stage 11 needs the gathered sums");
       c->oml_gath = a;
       return launch_oml_b(c, a, nranks);
-    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..5, 10 or 11");
+    default: QG_FAIL("qgcm_hip_slab_stage: stage must be 1..7, 10 or 11");
   }
 }
 
@@ -2481,7 +2483,8 @@ extern "C" int qgcm_hip_comm_probe(qgcm_hip_handle c, int reps, double *us) {
 
 // one distributed ocean step: three communication-free stages (the same calls SlabOcean.step makes through
 // qgcm_hip_slab_stage) and two exchanges, all ordered on c->stream; no host synchronisation
-static int slab_step(qgcm_hip_ctx *c, int s) {
+// next_follows: step s + 1 is executed by the same qgcm_hip_slab_steps call / captured block (its tendency may be started)
+static int slab_step(qgcm_hip_ctx *c, int s, bool next_follows) {
   QgSlabComm *m = c->sc_comm;
   const int r = m->rank, P = m->nranks;
   const size_t n = m->halo_len;
@@ -2499,7 +2502,9 @@ static int slab_step(qgcm_hip_ctx *c, int s) {
     if (qgcm_hip_slab_stage(c, 4, nullptr, nullptr, nullptr, r, P, 0)) return 1;
     HIPCHECK(hipStreamWaitEvent(c->stream, m->ev_halo, 0));
     m->pending = false;
-    if (qgcm_hip_slab_stage(c, 5, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
+    // the outer tile rows have run on the exchange's stream right behind the halo rows, beside the inner ones (below)
+    if (qgcm_hip_slab_stage(c, m->outer_done ? 7 : 5, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
+    m->outer_done = false;
   } else if (qgcm_hip_slab_stage(c, 1, m->th_send, nullptr, nullptr, r, P, 0)) return 1;
   NCCLCHECK(m->api, m->api->AllGather(m->th_send, m->th_gath, m->th_len, ncclDouble, m->comm, c->stream));
   // 2. both sweeps from the composed inflows (+ basin-wide area integrals), constraints, inverse row transform,
@@ -2545,6 +2550,20 @@ static int slab_step(qgcm_hip_ctx *c, int s) {
     if (rc) return 1;
   }
   if (ov) {
+    // The outer tile rows of step s + 1's tendency launch go out on the exchange's stream, right behind the halo rows
+    // they need: they run BESIDE the inner tile rows the handle's stream is computing (disjoint tiles of the same
+    // launch) instead of as a launch of their own after them - which cost a whole extra single-generation kernel per
+    // step (round 3: +23 us on one rank).  Only when step s + 1 belongs to this call: a caller that stops here may
+    // read the state, and the outer rows write into the buffer that holds qom.
+    m->outer_done = false;
+    if (next_follows) {
+      hipStream_t main_stream = c->stream;
+      c->stream = xs;
+      const int rc = qgcm_hip_slab_stage(c, 6, m->th_send, nullptr, nullptr, r, P, 0);
+      c->stream = main_stream;
+      if (rc) return 1;
+      m->outer_done = true;
+    }
     HIPCHECK(hipEventRecord(m->ev_halo, m->cstream));
     m->pending = true;
   }
@@ -2574,10 +2593,10 @@ static int get_slab_graph(qgcm_hip_ctx *c, int s0, hipGraphExec_t *out) {
   hipGraph_t graph;
   HIPCHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  for (int k = 0; k < kGraphBlock && !rc; ++k) rc = slab_step(c, s0 + k);
+  for (int k = 0; k < kGraphBlock && !rc; ++k) rc = slab_step(c, s0 + k, k + 1 < kGraphBlock);
   if (!rc) rc = slab_join(c);
   hipError_t e = hipStreamEndCapture(c->stream, &graph);
-  if (rc && c->sc_comm) c->sc_comm->pending = false;
+  if (rc && c->sc_comm) c->sc_comm->pending = c->sc_comm->outer_done = false;
   c->ip = ip0; // nothing ran: the rotation state is that of the block's first step
   c->iq = iq0;
   c->oml.is = is0;
@@ -2607,7 +2626,7 @@ extern "C" int qgcm_hip_slab_steps(qgcm_hip_handle c, int s0, int n) {
     n -= kGraphBlock;
   }
   for (; n > 0; --n, ++s)
-    if (slab_step(c, s)) return 1;
+    if (slab_step(c, s, n > 1)) return 1;
   return slab_join(c);
 }
 

@@ -66,6 +66,7 @@ struct QgSlabComm {
   // halo exchange overlapped with the inner tile rows of the next step's tendency launch (qgcm_hip_comm_set_overlap):
   // the exchange and the halo unpack run on cstream, forked from / joined to the handle's stream by events
   bool overlap = false, pending = false;
+  bool outer_done = false; // the pending exchange's stream has also run the outer tile rows of the next step's tendency
   hipStream_t cstream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_halo = nullptr;
 };
