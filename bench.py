@@ -35,7 +35,8 @@ WORKLOAD = "natl5"
 # P5 unpack 14 (box).  "own" = what this implementation's kernel has to move
 # (rotating time-level buffers: no qom/pom rewrite, no po re-read) - DESIGN.md.
 ALGO_FIELDS = {"k_tend": (24, 21), "k_dst_fwd": (6, 6), "k_thomas": (6, 6), "k_dst_inv": (6, 6),
-               "k_unpack": (14, 8), "k_constr": (0, 0), "k_cyc_bsums": (0, 0), "k_noop": (0, 0), "k_ocqbdy": (0, 0), "k_lf_average": (0, 0)}
+               "k_unpack": (14, 8), "k_constr": (0, 0), "k_cyc_bsums": (0, 0), "k_noop": (0, 0), "k_ocqbdy": (0, 0), "k_lf_average": (0, 0),
+               "k_oml": (0, 0), "k_oml_entoc": (0, 0)}
 
 
 def divert_stdout():
@@ -725,10 +726,22 @@ def main():
             ms = model.time_steps(args.steps, s0=301)
             pr2 = model.profile_steps(50, s0=301 + args.steps)
             st_ok = bool(np.isfinite(model.oml_get_state()[0]).all())
+            # `call oml` on the device: k_oml_step (reads sstm, sst, po(1), tauxo, tauyo, fnetoc, wekto; writes sst, the raw
+            # entrainment: 9 fields) and k_oml_entoc (reads the entrainment, writes entoc: 2 fields) - own bytes, live
+            # HIP-event brackets minus the calibrated bracket cost (src/omlsubs.F:47-763)
+            us_a = 1e3 * pr2["k_oml"][0] / max(pr2["k_oml"][1], 1) - bracket_us
+            us_b = 1e3 * pr2["k_oml_entoc"][0] / max(pr2["k_oml_entoc"][1], 1) - bracket_us
+            nT = cfg.nxto * cfg.nyto * 8.0
             out["with_mixed_layer"] = {"steps_per_s": round(args.steps / (ms * 1e-3), 2),
                                        "ms_per_step": round(ms / args.steps, 5), "state_finite": st_ok,
                                        "mixed_layer_us_per_step": round(1e3 * (ms / args.steps - ev_ms / args.steps), 3),
-                                       "oml_kernels_us_bracketed": round(1e3 * pr2["k_oml"][0] / max(pr2["k_oml"][1], 1) - bracket_us, 3)}
+                                       "oml_kernels_us_bracketed": round(us_a + us_b, 3),
+                                       "roofline": [{"bound": "hbm", "kernel": k, "achieved": round(f * nT / (u * 1e-6) / 1e9, 1),
+                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f * nT / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                     "avg_launch_us": round(u, 3), "algorithmic_bytes_per_launch": f * nT,
+                                                     "traffic": pmc_traffic(k, "pmc_traffic_oml.json"),
+                                                     "traffic_source": "committed rocprofv3 --pmc collection (profiles/pmc_traffic_oml.json), if any"}
+                                                    for k, f, u in (("k_oml_step", 9, us_a), ("k_oml_entoc", 2, us_b))]}
         except Exception as e:  # noqa: BLE001 - secondary figure only
             out["with_mixed_layer"] = {"error": repr(e)}
         # Secondary figure: BASELINE configs[2], the zonally cyclic Southern Ocean channel at 5 km (4609 x 577 x 3)

@@ -43,7 +43,16 @@
 #define TEND_NT 256
 #endif
 
-static_assert(TEND_TX % 2 == 0, "tend_point<.., PAIR> stores the new qo in pairs of neighbouring columns: tiles start on odd columns");
+// Tiles of the HBM-bound sizes (the instantiations without write-through stores, WTQ = false): twice as wide.  A row of a
+// 32-wide tile is two whole 128-byte lines per field instead of one, the radius-3 halo columns weigh half as much, and
+// at SOcn 5 km / the slabs of NAtl 1 km the kernel's reads come from HBM, not from the Infinity Cache: measured at
+// SOcn 5 km (profiles/r4_tend_shapes_socn5.log) 16 x 16: 100.6 us, 32 x 16 (256 threads, two rows per thread): 94.7,
+// 32 x 16 / 512 threads: 95.0, 64 x 8: 94.7, 64 x 4: 96.2, 32 x 8: 96.3, 16 x 32: 100.4 (+), 32 x 32: 101.2.  At NAtl 5 km
+// (cache resident, write-through pairs) the 16 x 16 tile stays: resident workgroups matter more there (see above).
+#ifndef TEND_TX_WIDE
+#define TEND_TX_WIDE 32
+#endif
+static_assert(TEND_TX % 2 == 0 && TEND_TX_WIDE % 2 == 0, "tend_point<.., PAIR> stores the new qo in pairs of neighbouring columns: tiles start on odd columns");
 
 template <bool CYC>
 __device__ __forceinline__ int tend_wrap(int gi, int nxt) {
@@ -61,13 +70,13 @@ struct TendTiling {
   int nedge;      // edge workgroups
 };
 
-template <bool CYC>
+template <bool CYC, int TX = TEND_TX>
 __host__ __device__ __forceinline__ TendTiling tend_tiling(const QgGeom &g) {
   TendTiling T;
   const int rows = g.jhi - g.jlo + 1;
-  T.ecol = (!CYC && g.nx % TEND_TX == 1 && g.nx > 1) ? 1 : 0;
+  T.ecol = (!CYC && g.nx % TX == 1 && g.nx > 1) ? 1 : 0;
   T.erow = (!CYC && rows % TEND_TY == 1 && rows > 1 && g.jhi + g.joff == g.nyg) ? 1 : 0;
-  T.gx = T.ecol ? g.nx / TEND_TX : (g.nx + TEND_TX - 1) / TEND_TX;
+  T.gx = T.ecol ? g.nx / TX : (g.nx + TX - 1) / TX;
   T.gy = T.erow ? rows / TEND_TY : (rows + TEND_TY - 1) / TEND_TY;
   T.imax = T.ecol ? g.nx - 1 : g.nx;
   T.jmax = T.erow ? g.jhi - 1 : g.jhi;
@@ -190,8 +199,11 @@ template <int NL, bool CYC, bool WTQ>
 #endif
 __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P, const QgCycSumParams S,
                                                                      const QgOmlFinal F) {
+#ifndef TEND_EXPERIMENT // (tile-shape A/B builds without the mixed layer: profiles/r4_tend_shapes_socn5.log)
   static_assert(TEND_NT == OML_NT, "oml_final_block runs in workgroup 0 of this kernel");
-  constexpr int TX = TEND_TX, TY = TEND_TY;
+#endif
+  constexpr int TX = WTQ ? TEND_TX : TEND_TX_WIDE, TY = TEND_TY;
+  static_assert(TEND_NT % TX == 0 && TY % (TEND_NT / TX) == 0, "whole rows of threads, whole rows per thread");
   constexpr int W3 = TX + 6, H3 = TY + 6; // pom tile, halo 3
   constexpr int W2 = TX + 4, H2 = TY + 4; // d2 tile, halo 2
   constexpr int W1 = TX + 2, H1 = TY + 2; // d4 / po / qo tiles, halo 1
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   // Box grids have nx = 64*g + 1 columns and (whole basin) 8*h + 1 rows: the last column and the last
   // row are walls whose update is point-wise (no stencil), so they are peeled off into a few "edge"
   // workgroups instead of a whole extra column / row of nearly empty tiles (tend_edge below).
-  const TendTiling T = tend_tiling<CYC>(P.g);
+  const TendTiling T = tend_tiling<CYC, TX>(P.g);
   const int gx = T.gx;
   const int ntiles = gx * (P.trows ? P.trows : T.gy); // (a window of the tile rows, or all of them)
   const int per_xcd = (ntiles + 7) / 8;

@@ -45,9 +45,10 @@ static thread_local char g_err[512] = "";
     if (e_ != hipSuccess) QG_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_OML, KN_NOOP, KN_NOOP_TRAIN, KN_COUNT };
+enum { KN_TEND = 0, KN_BSUMS, KN_DSTF, KN_THOMAS, KN_DSTI, KN_CONSTR, KN_UNPACK, KN_OCQBDY, KN_LFAVG, KN_OML, KN_OML_ENTOC, KN_NOOP, KN_NOOP_TRAIN, KN_COUNT };
+// (k_oml = k_oml_step, the sst step + raw entrainment; k_oml_entoc = the entrainment on the p grid)
 static const char *kKernelNames[KN_COUNT] = {"k_tend",   "k_cyc_bsums", "k_dst_fwd", "k_thomas", "k_dst_inv",
-                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average", "k_oml", "k_noop", "k_noop_train"};
+                                             "k_constr", "k_unpack",  "k_ocqbdy", "k_lf_average", "k_oml", "k_oml_entoc", "k_noop", "k_noop_train"};
 
 // Device copy of the Thomas pivot tables of one set of diagonals (see QgThomasParams / build_pivots).
 struct QgThomasTab {
@@ -102,6 +103,7 @@ struct qgcm_hip_ctx {
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
+  bool tend_wide;         // QGCM_HIP_TEND_WIDE=1: the tendency kernel's HBM-bound instantiation (32-wide tiles, plain stores) at any size (tests)
   std::vector<double> bd2oc;
   // profiling
   hipError_t timer_err = hipSuccess;
@@ -282,6 +284,8 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     c->no_fused_unpack = f && f[0] == '1';
     const char *fc = getenv("QGCM_HIP_NO_FUSED_CONSTR");
     c->no_fused_constr = fc && fc[0] == '1';
+    const char *tw = getenv("QGCM_HIP_TEND_WIDE");
+    c->tend_wide = tw && tw[0] == '1';
   }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
@@ -894,7 +898,12 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   P.rspl = c->rspl;
   P.tdc1 = pr.tdto * c->c1_spl; // tdto*c1_spl, src/qgosubs.F:204
   for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
-  const TendTiling T = g.cyc ? tend_tiling<true>(g) : tend_tiling<false>(g);
+  // write-through pair stores of the new qo and 16-wide tiles while the step's working set (~ 7 nl - 1 fields) stays in the
+  // 256 MiB Infinity Cache (NAtl 5 km: 150 MB: -1 us per step; SOcn 5 km's 425 MB: +8 us); plain stores and 32-wide
+  // tiles at the HBM-bound sizes (k_tend.h)
+  const bool wtq = (double)g.fstride * 8.0 * (7 * g.nl - 1) < 200.0e6 && !c->tend_wide;
+  const TendTiling T = g.cyc ? (wtq ? tend_tiling<true, TEND_TX>(g) : tend_tiling<true, TEND_TX_WIDE>(g))
+                             : (wtq ? tend_tiling<false, TEND_TX>(g) : tend_tiling<false, TEND_TX_WIDE>(g));
   if (part != TEND_ALL && T.gy < 3) QG_FAIL("k_tend: a slab of fewer than three tile rows cannot be split");
   if (part == TEND_INNER) { P.trow0 = 1; P.trows = T.gy - 2; P.tstride = 1; }
   if (part == TEND_OUTER) { P.trow0 = 0; P.trows = 2; P.tstride = T.gy - 1; P.upd_dpi = 0; }
@@ -914,9 +923,6 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   const int nextra = part == TEND_INNER ? 0 : (g.cyc ? g.nl * 2 * BSUM_NB : T.nedge);
   dim3 grid(8 * ((ntiles + 7) / 8) + nextra); // 1-D: the kernel maps blockIdx -> tile per XCD band, then edge / line-sum work
   KTimer t(c, KN_TEND);
-  // write-through pair stores of the new qo while the step's working set (~ 7 nl - 1 fields) stays in the 256 MiB
-  // Infinity Cache (NAtl 5 km: 150 MB: -1 us per step; SOcn 5 km's 425 MB: +8 us - k_tend.h)
-  const bool wtq = (double)g.fstride * 8.0 * (7 * g.nl - 1) < 200.0e6;
 #define QG_TEND(NLV)                                                                                       \
   if (g.cyc && wtq) hipLaunchKernelGGL((k_tend<NLV, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);    \
   else if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);     \
@@ -1624,8 +1630,14 @@ static int launch_oml_b(qgcm_hip_ctx *c, const double *gath3, int nranks) {
 
 // with_final = false: the final reduction rides in workgroup 0 of the tendency launch that follows (one_step)
 static int launch_oml(qgcm_hip_ctx *c, bool with_final = true) {
-  KTimer t(c, KN_OML);
-  if (launch_oml_a(c, nullptr) || launch_oml_b(c, nullptr, 1)) return 1;
+  {
+    KTimer t(c, KN_OML);
+    if (launch_oml_a(c, nullptr)) return 1;
+  }
+  {
+    KTimer t(c, KN_OML_ENTOC);
+    if (launch_oml_b(c, nullptr, 1)) return 1;
+  }
   if (with_final) {
     QgOmlFinal F;
     fill_oml_final(c, F, true);

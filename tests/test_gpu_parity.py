@@ -1008,6 +1008,55 @@ def test_full_size_natl1_slabs_vs_oracle():
         o.close()
 
 
+@pytest.mark.parametrize("name", ["box_tiny", "cyc_tiny", "box_small", "box_tiny_spl"])
+def test_wide_tendency_tiles_are_bit_exact(name, monkeypatch):
+    """At the HBM-bound sizes (SOcn 5 km, the slabs of NAtl 1 km) the tendency kernel runs 32-wide tiles with plain stores
+    (chosen by size in launch_tend); QGCM_HIP_TEND_WIDE=1 forces that instantiation at the fixture sizes: qgostep bit
+    for bit the reference, whole steps as the default instantiation, two y-slabs with the split (inner / outer) launch."""
+    import torch
+    from qgcm_hip import OceanModel
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset(name)
+    g = load_golden(name)
+    ref = OceanModel(cfg)
+    apply_inputs(ref, g, cfg)
+    ref.steps(30, s0=1)
+    want = ref.get_state()
+    ref.close()
+    monkeypatch.setenv("QGCM_HIP_TEND_WIDE", "1")
+    m = OceanModel(cfg)
+    slabs = []
+    try:
+        apply_inputs(m, g, cfg)
+        if "qgostep_po" in g:
+            load_snapshot(m, g, "init")
+            m.qgostep()
+            e = state_errs(m, g, "qgostep")
+            assert all(v == 0.0 for v in e.values()), e
+            apply_inputs(m, g, cfg)
+        st0, sc0 = m.get_state(), m.get_scalars()
+        m.steps(30, s0=1)
+        for x, y in zip(m.get_state(), want):
+            assert np.array_equal(x, y)
+        if not cfg.cyclic and cfg.l_spl == 0.0:
+            consts = global_consts(cfg)
+            slabs = [HipSlab(cfg, consts, g0, g1, r, 2, sync_each_call=True) for r, (g0, g1) in enumerate(partition(cfg.nypo, 2))]
+            so = SlabOcean(cfg, slabs, LocalComm(2, after=torch.cuda.synchronize))
+            so.homsol()
+            so.scatter_state(st0[0], st0[1], st0[2], st0[3], g["in_wekpo"], g["in_entoc"], g["in_xon"], sc0)
+            so.steps(30, s0=1)
+            got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+            for g0, g1, fields in so.gather_local():
+                for dst, src in zip(got, fields):
+                    dst[:, g0 - 1:g1, :] = src
+            for f, x, y in zip(FIELDS, got, want):
+                assert relerr(x, y) < 1e-10, f
+    finally:
+        for sl in slabs:
+            sl.close()
+        m.close()
+
+
 def test_natl5_long_run_within_the_references_own_thread_spread():
     """SURVEY 8(d)'s long-run tolerances at BASELINE's full size (NAtl 5 km, 961 x 961 x 3, configs[1]): after 160
     ocean steps <= 1e-9, after 1600 (ten model days) <= 1e-7 of the field's max-norm, against samples of the REFERENCE
