@@ -4,8 +4,9 @@
 #       pass 1  rocprofv3 --kernel-trace --stats        -> kernel durations
 #       pass 2  rocprofv3 --pmc FETCH_SIZE              (own pass, kernel-trace only)
 #       pass 3  rocprofv3 --pmc WRITE_SIZE              (own pass)
-#   socn5 / atmos / natl1_slabs / natl1_one_slab: profiles/tools/run_workload.py <what> under the same passes (the HBM-bound
-#       configuration BASELINE configs[2], the atmospheric channel, NAtl 1 km as eight slabs); PMC passes for socn5 only
+#   socn5 / atmos / natl1_slabs / natl1_one_slab / natl5_one_slab_of_8 / natl5_oml: profiles/tools/run_workload.py <what> under
+#       the same passes (the HBM-bound configuration BASELINE configs[2], the atmospheric channel, NAtl 1 km as eight slabs,
+#       one slab of the headline basin, the mixed layer); PMC passes for socn5, natl1_slabs and natl5_oml
 # then profiles/pmc_reduce.py turns the counter dumps into per-kernel HBM-side bytes per launch
 # (FETCH_SIZE x2 correction for gfx950, /opt/skills/guides/MI355X_MICROARCH.md).  Results land under
 # gpurun_out/<tag>_<what>/ ; copy what is to be judged into profiles/.
@@ -25,9 +26,9 @@ if [ "$WHAT" = natl5 ]; then
   grep '^{' "$OUT/bench_under_rocprof.log" > "$OUT/bench_under_rocprof.json" || true
 else
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 profiles/tools/run_workload.py $WHAT 200 > "$OUT/run.log" 2>&1
-  if [ "$WHAT" = socn5 ]; then
+  if [ "$WHAT" = socn5 ] || [ "$WHAT" = natl1_slabs ] || [ "$WHAT" = natl5_oml ]; then
     for C in FETCH_SIZE WRITE_SIZE; do
-      timeout -k 10 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 profiles/tools/run_workload.py $WHAT 60 > "$OUT/pmc_$C.log" 2>&1
+      timeout -k 10 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -- python3 profiles/tools/run_workload.py $WHAT 30 > "$OUT/pmc_$C.log" 2>&1
     done
   fi
 fi

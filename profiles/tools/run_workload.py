@@ -1,5 +1,6 @@
 """Steps one workload on cuda:0 for rocprofv3 (profiles/collect.sh): `python3 profiles/tools/run_workload.py <what> [steps]`
   socn5 / natl5 / <any ocean preset>   whole-domain handle, Gaussian-eddy IC + synthetic wind (+ k_copy calibration launches)
+  natl5_oml / <preset>_oml             the same with the ocean mixed layer on the device (k_oml_step, k_oml_entoc)
   atmos                                385 x 97 x 3 atmospheric channel of double_gyre_coupled
   natl1_slabs                          NAtl 1 km as eight y-slabs (virtual ranks on this one GPU, every kernel HBM-cold)
   natl1_one_slab                       the same set-up, then ONE middle slab stepped alone: its fields stay in the
@@ -105,8 +106,18 @@ elif what in ("natl1_slabs", "natl1_one_slab", "natl5_slabs", "natl5_one_slab_of
     print("finite", all(np.isfinite(f).all() for _, _, fs in so.gather_local() for f in fs))
 else:
     from qgcm_hip import OceanModel, preset, synth
+    with_oml = what.endswith("_oml")       # e.g. natl5_oml: the same with the ocean mixed layer on the device (`call oml`)
+    what = what[:-4] if with_oml else what
     cfg = preset(what)
     m = OceanModel(cfg)
+    if with_oml:
+        from qgcm_hip import oml_preset
+        om = oml_preset(cfg)
+        sst, sstm, fnet, txo, tyo = synth.mixed_layer_fields(cfg, om)
+        wekto, _ = synth.wekpo_from_tau(cfg, txo, tyo)
+        m.oml_init(om)
+        m.oml_set_state(sst, sstm)
+        m.oml_set_forcing(fnet, wekto, txo, tyo)
     po = synth.gaussian_eddy(cfg)
     tx, ty = synth.wind_stress(cfg)
     _, wek = synth.wekpo_from_tau(cfg, tx, ty)
@@ -114,9 +125,9 @@ else:
     m.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
     if cfg.cyclic:
         m.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
-    m.steps(100, s0=1)
-    ms = m.time_steps(400, s0=101)
-    print("%s: %.2f us per step (graph replay)" % (what, 1e3 * ms / 400))
-    m.profile_steps(nsteps, s0=501)   # eager launches with named kernels (brackets between them)
+    m.steps(150, s0=1)
+    ms = m.time_steps(400, s0=151)
+    print("%s%s: %.2f us per step (graph replay)" % (what, " with the mixed layer" if with_oml else "", 1e3 * ms / 400))
+    m.profile_steps(nsteps, s0=551)   # eager launches with named kernels (brackets between them)
     m.copy_bandwidth(1 << 30, 3)      # 1 GiB k_copy launches: the calibration of the FETCH_SIZE correction
     print("finite", bool(np.isfinite(m.get_state()[0]).all()))
