@@ -118,7 +118,7 @@ __device__ __forceinline__ void oml_block_sums(double *v, double *sm, int tid) {
   for (int q = 0; q < NV; ++q) v[q] = (sm[q * 4] + sm[q * 4 + 1]) + (sm[q * 4 + 2] + sm[q * 4 + 3]);
 }
 
-// grid: (ceil(nxt/64), ceil(nyt/16)), block 256 = 64 x 4; thread rows j0 + 4 ty + r
+// grid: (ceil(nxt/64), ceil(nyt/16)), block 256 = 64 x 4; thread rows j0 + ty + 4 r
 __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
   constexpr int TH = OML_TY * OML_RPT;      // tile rows
   constexpr int DW = OML_TX + 2, DH = TH + 2; // del2t tile with a halo of one
@@ -147,10 +147,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
 #define VF(ii, jj) (uvgfac * (PO1((ii) + 1, jj) - PO1(ii, jj)) - rhf0hm * (TXo((ii) + 1, jj) + TXo(ii, jj)))
 #pragma unroll
   for (int r = 0; r < OML_RPT; ++r) {
-    // a thread's rows are ADJACENT (ly0*RPT + r): the p-grid operands of the face velocities (po, tauxo, tauyo at rows
-    // j, j+1) and the sst column of one row are the next row's too - 56 instead of 80 distinct loads per thread
-    // (the unrolled body lets the compiler share them); the kernel is bound by the L1 / TA rate of those loads
-    const int ly = ly0 * OML_RPT + r;
+    const int ly = ly0 + OML_TY * r;
     const int j = j0 + ly;
     if (i > nxt || j > P.jT1) continue;
     const int G = j + P.joff; // global T row
@@ -218,7 +215,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
   }
 }
 
-// grid: (ceil(nx/64), ceil(ny/(16*OML_ERR))), block 256 = 64 x 4, thread rows j0 + 4 ty + r of OML_ERR tile rows
+// grid: (ceil(nx/64), ceil(ny/(16*OML_ERR))), block 256 = 64 x 4, thread rows j0 + ty + 4 r of OML_ERR tile rows
 __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
   __shared__ double redm[4], red[12];
   const int tid = threadIdx.x;
@@ -234,7 +231,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
     const int rr = q / OML_RPT, r = q % OML_RPT;
-    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) * OML_RPT + r + P.jP0; // owned p rows (adjacent per thread)
+    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + P.jP0; // owned p rows
     ncell[q] = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) raw[q][e] = 0.0;
@@ -272,7 +269,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_entoc(const QgOmlParams P) {
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
     const int rr = q / OML_RPT, r = q % OML_RPT;
-    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) * OML_RPT + r + P.jP0;
+    const int j = (blockIdx.y * OML_ERR + rr) * (OML_TY * OML_RPT) + (tid / OML_TX) + OML_TY * r + P.jP0;
     if (i > nx || j > P.jP1) continue;
     const int G = j + P.joff;
     const double x0 = raw[q][0] - xmean, x1 = raw[q][1] - xmean, x2 = raw[q][2] - xmean, x3 = raw[q][3] - xmean;
