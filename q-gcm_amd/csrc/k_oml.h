@@ -10,9 +10,9 @@
 // Without it the host would need po(:,:,1) down and entoc up over PCIe every step (2 x 7.4 MB at 5 km).
 //
 // Three launches:
-//   k_oml_step   one thread per T point: rhs (every expression in the reference's operand order, contraction
-//                off => sst is bitwise the reference's), new sst into the spare buffer (the sst buffers
-//                rotate: new -> sst, sst -> sstm), raw entrainment xfo, per-workgroup partial sums
+//   k_oml_step   one thread per T point, operand fields staged through LDS: rhs (every expression in the reference's
+//                operand order, contraction off => sst is bitwise the reference's), new sst into the spare buffer (the
+//                sst buffers rotate: new -> sst, sst -> sstm), raw entrainment xfo, per-workgroup partial sums
 //   k_oml_entoc  every workgroup re-reduces the partials in the same fixed order (no extra launch, same mean
 //                everywhere), entoc = average of (xfo - mean) onto the p points, partials of xintp / line sums.
 //                One generation of workgroups (OML_ERR tile rows each): the re-reduction is a ~2 us prologue that
@@ -60,49 +60,6 @@ struct QgOmlParams {
   double uvgfac, rhf0hm, hdxom1, d2tfac, d4tfac, hmoinv, dtoinv, entfac, tdto, rrcpoc, toc1, tsbdy, tnbdy, ocnorm, dxo, dyo;
 };
 
-// del2t(i,j) of the lagged sst, boundary variants of src/omlsubs.F:297-300 (W), 331-346 (E), 403-422 (S),
-// 437-454 (N), 466-647 (corners); the operand order of every case is the reference's.
-__device__ __forceinline__ double oml_del2t(const QgOmlParams &P, int i, int j) {
-  const int nxt = P.nxt;
-  const double *T = P.sstm;
-  const long ld = P.ldt;
-  const bool hasW = (i > 1) || P.cyc, hasE = (i < nxt) || P.cyc;
-  const double cc = T[(long)(j - 1) * ld + (i - 1)];
-  const double w = hasW ? T[(long)(j - 1) * ld + ((i > 1 ? i - 1 : nxt) - 1)] : 0.0;
-  const double e = hasE ? T[(long)(j - 1) * ld + ((i < nxt ? i + 1 : 1) - 1)] : 0.0;
-  double acc, n;
-  const int G = j + P.joff; // global T row: the boundary variants belong to the basin's first and last row
-  if (G == 1) { // W, E, N, tsbdy
-    const double nn = T[(long)j * ld + (i - 1)];
-    if (hasW) { acc = w; n = 1.0; if (hasE) { acc = acc + e; n = 2.0; } }
-    else { acc = e; n = 1.0; } // a row has at least one x neighbour
-    acc = acc + nn; n += 1.0;
-    if (P.sb) { acc = acc + P.tsbdy; n += 1.0; }
-    return acc - n * cc;
-  }
-  const double s = T[(long)(j - 2) * ld + (i - 1)];
-  if (G == P.nytg) {
-    if (P.cyc && i == nxt && P.nb) return s + w + e - 4.0 * cc + P.tnbdy; // :630-631
-    acc = s; n = 1.0; // S, W, tnbdy, E
-    if (hasW) { acc = acc + w; n += 1.0; }
-    if (P.nb) { acc = acc + P.tnbdy; n += 1.0; }
-    if (hasE) { acc = acc + e; n += 1.0; }
-    return acc - n * cc;
-  }
-  acc = s; n = 1.0; // S, W, E, N
-  if (hasW) { acc = acc + w; n += 1.0; }
-  if (hasE) { acc = acc + e; n += 1.0; }
-  acc = acc + T[(long)j * ld + (i - 1)]; n += 1.0;
-  return acc - n * cc;
-}
-
-// del2t with the dummy columns of src/omlsubs.F:349-357 (box: copy of the edge column, cyclic: wrap)
-__device__ __forceinline__ double oml_del2t_x(const QgOmlParams &P, int i, int j) {
-  if (i < 1) i = P.cyc ? P.nxt : 1;
-  else if (i > P.nxt) i = P.cyc ? 1 : P.nxt;
-  return oml_del2t(P, i, j);
-}
-
 // Sums of NV values over the 256 threads of a workgroup in a fixed order (xor butterfly inside each wave, then the
 // four wave totals left to right); every thread returns with the totals. One barrier; sm is (NV x 4) doubles.
 template <int NV>
@@ -118,62 +75,175 @@ __device__ __forceinline__ void oml_block_sums(double *v, double *sm, int tid) {
   for (int q = 0; q < NV; ++q) v[q] = (sm[q * 4] + sm[q * 4 + 1]) + (sm[q * 4 + 2] + sm[q * 4 + 3]);
 }
 
-// grid: (ceil(nxt/64), ceil(nyt/16)), block 256 = 64 x 4; thread rows j0 + ty + 4 r
+// grid: (ceil(nxt/64), ceil(rows/OML_SH)), block 256 = 64 x 4; thread rows j0 + ty + 4 r, r < OML_SH/4
+// Round 4: every operand field goes through LDS.  The round-1 kernel read its stencils straight from global memory: five
+// loads of the lagged sst per Del^2 value (five trips of a rolled loop) and ~20 per T point, i.e. ~9 dependent memory
+// round trips per workgroup and 31 eight-byte loads per point through the L1 / TA path - 22.6 us for 66.5 MB of compulsory
+// traffic (PMC: 89 MB; profiles/r4_natl5_oml_*).  Now: ONE round trip stages the tile of sstm (halo 2), sst (halo 1) and
+// the p-grid tiles of po(1), tauxo, tauyo (columns i .. i+1, rows j .. j+1), all loads in flight together, zonal wrap /
+// wall clamp applied while staging; Del^2, the face velocities and the advection read LDS.  Arithmetic unchanged (every
+// expression in the reference's operand order): sst stays bitwise the reference's.
+#ifndef OML_SH
+#define OML_SH 8 // tile rows (31 KB of LDS: five workgroups per CU; 16 rows: 56 KB, two per CU)
+#endif
 __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
-  constexpr int TH = OML_TY * OML_RPT;      // tile rows
-  constexpr int DW = OML_TX + 2, DH = TH + 2; // del2t tile with a halo of one
-  __shared__ double sD[DH * DW];
+  constexpr int TH = OML_SH, RPT = TH / OML_TY;
+  constexpr int MW = OML_TX + 4, MH = TH + 4; // sstm tile, halo 2: local (lx, ly) <-> T point (i0 - 2 + lx, j0 - 2 + ly)
+  constexpr int SW = OML_TX + 2, SH = TH + 2; // sst tile, halo 1
+  constexpr int PW = OML_TX + 1, PH = TH + 1; // p-grid tiles: p points (i0 + lx, j0 + ly)
+  constexpr int DW = OML_TX + 2, DH = TH + 2; // del2t tile, halo 1
+  __shared__ double sM[MH * MW], sS[SH * SW], sP[PH * PW], sX[PH * PW], sY[PH * PW], sD[DH * DW];
   __shared__ double red[12];
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * OML_TX + 1, j0 = blockIdx.y * TH + P.jX0; // local rows jX0..jT1
   const int lx0 = tid % OML_TX, ly0 = tid / OML_TX;
   const int i = i0 + lx0;
-  const int nxt = P.nxt, nyt = P.nyt;
-  // del2t of the tile and its halo, each value once (dummy columns by the wall / wrap rule)
-  for (int idx = tid; idx < DH * DW; idx += OML_NT) {
-    const int gi = i0 - 1 + idx % DW, gj = j0 - 1 + idx / DW;
-    const int gG = gj + P.joff;
-    sD[idx] = (gG >= 1 && gG <= P.nytg && gj >= 1 && gj <= nyt && gi >= 0 && gi <= nxt + 1) ? oml_del2t_x(P, gi, gj) : 0.0;
+  const int nxt = P.nxt, nyt = P.nyt, cyc = P.cyc;
+  const long ldt = P.ldt, ldx = P.ldx;
+  // T column that local column position gi stands for: zonal wrap (cyclic) or the wall column itself (box: the dummy
+  // columns of src/omlsubs.F:349-357 copy the edge column; nothing else reads a clamped value)
+  // (modulo, not one subtraction: the last tile of a narrow channel reaches more than one period past the edge - those
+  //  positions are never used, but their addresses must stay inside the row)
+  auto tcol = [&](int gi) { return cyc ? ((gi - 1) % nxt + nxt) % nxt + 1 : (gi < 1 ? 1 : (gi > nxt ? nxt : gi)); };
+  auto trow = [&](int gj) { return gj < 1 ? 1 : (gj > nyt ? nyt : gj); }; // (rows outside the local array: address clamped, value unused)
+  // ---- stage: all loads of a thread in flight together
+  {
+    constexpr int NM = (MH * MW + OML_NT - 1) / OML_NT, NS = (SH * SW + OML_NT - 1) / OML_NT, NP = (PH * PW + OML_NT - 1) / OML_NT;
+    double vm[NM], vs[NS], vp[NP], vx[NP], vy[NP];
+#pragma unroll
+    for (int e = 0; e < NM; ++e) {
+      const int idx = tid + e * OML_NT, lx = idx % MW, ly = idx / MW;
+      vm[e] = P.sstm[(long)(trow(j0 - 2 + (ly < MH ? ly : 0)) - 1) * ldt + (tcol(i0 - 2 + lx) - 1)];
+    }
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      const int idx = tid + e * OML_NT, lx = idx % SW, ly = idx / SW;
+      vs[e] = P.sst[(long)(trow(j0 - 1 + (ly < SH ? ly : 0)) - 1) * ldt + (tcol(i0 - 1 + lx) - 1)];
+    }
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int idx = tid + e * OML_NT, lx = idx % PW, ly = idx / PW;
+      const int pi = i0 + lx > P.nx ? P.nx : i0 + lx, pj0 = j0 + (ly < PH ? ly : 0), pj = pj0 > P.ny ? P.ny : pj0;
+      const long o = (long)(pj - 1) * ldx + (pi - 1);
+      vp[e] = P.po1[o];
+      vx[e] = P.taux[o];
+      vy[e] = P.tauy[o];
+    }
+#pragma unroll
+    for (int e = 0; e < NM; ++e) {
+      const int idx = tid + e * OML_NT;
+      if (idx < MH * MW) sM[idx] = vm[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      const int idx = tid + e * OML_NT;
+      if (idx < SH * SW) sS[idx] = vs[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int idx = tid + e * OML_NT;
+      if (idx < PH * PW) {
+        sP[idx] = vp[e];
+        sX[idx] = vx[e];
+        sY[idx] = vy[e];
+      }
+    }
+  }
+  // pointwise operands of this thread's own points, requested before the barrier
+  double e_fnet[RPT], e_wk[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int j = j0 + ly0 + OML_TY * r;
+    const bool in = i <= nxt && j <= P.jT1;
+    const long o = in ? (long)(j - 1) * ldt + (i - 1) : 0;
+    e_fnet[r] = P.fnet[o];
+    e_wk[r] = P.wekto[o];
   }
   __syncthreads();
-  const long ldt = P.ldt, ldx = P.ldx;
+  // ---- del2t of the tile and its halo, each value once, from the sstm tile.  Boundary variants of src/omlsubs.F:297-300
+  // (W), 331-346 (E), 403-422 (S), 437-454 (N), 466-647 (corners), the operand order of every case the reference's; the
+  // dummy columns by the wall / wrap rule (:349-357): a box evaluates the wall column again, a channel the wrapped one
+  for (int idx = tid; idx < DH * DW; idx += OML_NT) {
+    const int gi = i0 - 1 + idx % DW, gj = j0 - 1 + idx / DW;
+    const int G = gj + P.joff; // global T row: the boundary variants belong to the basin's first and last row
+    double val = 0.0;
+    if (G >= 1 && G <= P.nytg && gj >= 1 && gj <= nyt && gi >= 0 && gi <= nxt + 1) {
+      const int ie = tcol(gi);                    // the T column evaluated
+      const int lx = (cyc ? gi : ie) - (i0 - 2);  // ... and where its neighbourhood sits in the tile
+      const double *T = &sM[(gj - (j0 - 2)) * MW + lx];
+      const bool hasW = (ie > 1) || cyc, hasE = (ie < nxt) || cyc;
+      const double cc = T[0];
+      const double w = hasW ? T[-1] : 0.0;
+      const double e = hasE ? T[1] : 0.0;
+      double acc, n;
+      if (G == 1) { // W, E, N, tsbdy
+        const double nn = T[MW];
+        if (hasW) { acc = w; n = 1.0; if (hasE) { acc = acc + e; n = 2.0; } }
+        else { acc = e; n = 1.0; } // a row has at least one x neighbour
+        acc = acc + nn; n += 1.0;
+        if (P.sb) { acc = acc + P.tsbdy; n += 1.0; }
+        val = acc - n * cc;
+      } else {
+        const double s = T[-MW];
+        if (G == P.nytg) {
+          if (cyc && ie == nxt && P.nb) val = s + w + e - 4.0 * cc + P.tnbdy; // :630-631
+          else {
+            acc = s; n = 1.0; // S, W, tnbdy, E
+            if (hasW) { acc = acc + w; n += 1.0; }
+            if (P.nb) { acc = acc + P.tnbdy; n += 1.0; }
+            if (hasE) { acc = acc + e; n += 1.0; }
+            val = acc - n * cc;
+          }
+        } else {
+          acc = s; n = 1.0; // S, W, E, N
+          if (hasW) { acc = acc + w; n += 1.0; }
+          if (hasE) { acc = acc + e; n += 1.0; }
+          acc = acc + T[MW]; n += 1.0;
+          val = acc - n * cc;
+        }
+      }
+    }
+    sD[idx] = val;
+  }
+  __syncthreads();
   const double uvgfac = P.uvgfac, rhf0hm = P.rhf0hm, hdxom1 = P.hdxom1;
   double sxfo = 0.0, scfr = 0.0, scen = 0.0;
-#define PO1(ii, jj) P.po1[(long)((jj)-1) * ldx + ((ii)-1)]
-#define TXo(ii, jj) P.taux[(long)((jj)-1) * ldx + ((ii)-1)]
-#define TYo(ii, jj) P.tauy[(long)((jj)-1) * ldx + ((ii)-1)]
-#define ST(ii, jj) P.sst[(long)((jj)-1) * ldt + ((ii)-1)]
+  // local accessors: p points (ii, jj) with ii in i .. i+1, jj in j .. j+1; T points (ii, jj) within one of (i, j)
+#define PO1(ii, jj) sP[((jj)-j0) * PW + ((ii)-i0)]
+#define TXo(ii, jj) sX[((jj)-j0) * PW + ((ii)-i0)]
+#define TYo(ii, jj) sY[((jj)-j0) * PW + ((ii)-i0)]
+#define STL(di, jj) sS[((jj)-(j0 - 1)) * SW + (lx0 + 1 + (di))]
 #define UF(ii, jj) (-uvgfac * (PO1(ii, (jj) + 1) - PO1(ii, jj)) + rhf0hm * (TYo(ii, (jj) + 1) + TYo(ii, jj)))
 #define VF(ii, jj) (uvgfac * (PO1((ii) + 1, jj) - PO1(ii, jj)) - rhf0hm * (TXo((ii) + 1, jj) + TXo(ii, jj)))
 #pragma unroll
-  for (int r = 0; r < OML_RPT; ++r) {
+  for (int r = 0; r < RPT; ++r) {
     const int ly = ly0 + OML_TY * r;
     const int j = j0 + ly;
     if (i > nxt || j > P.jT1) continue;
     const int G = j + P.joff; // global T row
     // ---- advection, src/omlsubs.F:281-346 (rows), 370-456 (S/N rows), 458-700 (corners) ----
     double um, tm, up, tp;
-    if (i == 1 && !P.cyc) { um = 0.0; tm = 0.0; }
-    else { um = UF(i, j); tm = ST(i > 1 ? i - 1 : nxt, j) + ST(i, j); }
-    if (i == nxt && !P.cyc) { up = 0.0; tp = 0.0; }
-    else { up = UF(i + 1, j); tp = ST(i, j) + ST(i < nxt ? i + 1 : 1, j); }
+    if (i == 1 && !cyc) { um = 0.0; tm = 0.0; }
+    else { um = UF(i, j); tm = STL(-1, j) + STL(0, j); }
+    if (i == nxt && !cyc) { up = 0.0; tp = 0.0; }
+    else { up = UF(i + 1, j); tp = STL(0, j) + STL(1, j); }
     const double hxadv = hdxom1 * (up * tp - um * tm);
     double hyadv;
     if (G == 1) {
-      const double vp = VF(i, j + 1), tp2 = ST(i, j) + ST(i, j + 1);
+      const double vp = VF(i, j + 1), tp2 = STL(0, j) + STL(0, j + 1);
       if (P.sb) {
-        const double vm = -rhf0hm * (TXo(i + 1, j) + TXo(i, j)), tm2 = ST(i, j) + P.tsbdy;
+        const double vm = -rhf0hm * (TXo(i + 1, j) + TXo(i, j)), tm2 = STL(0, j) + P.tsbdy;
         hyadv = hdxom1 * (vp * tp2 - vm * tm2);
       } else hyadv = hdxom1 * (vp * tp2);
     } else if (G == P.nytg) {
-      const double vm = VF(i, j), tm2 = ST(i, j - 1) + ST(i, j);
+      const double vm = VF(i, j), tm2 = STL(0, j - 1) + STL(0, j);
       if (P.nb) {
-        const double vp = -rhf0hm * (TXo(i + 1, j + 1) + TXo(i, j + 1)), tp2 = ST(i, j) + P.tnbdy;
+        const double vp = -rhf0hm * (TXo(i + 1, j + 1) + TXo(i, j + 1)), tp2 = STL(0, j) + P.tnbdy;
         hyadv = hdxom1 * (vp * tp2 - vm * tm2);
       } else hyadv = hdxom1 * (-vm * tm2);
     } else {
       const double vm = VF(i, j), vp = VF(i, j + 1);
-      hyadv = hdxom1 * (vp * (ST(i, j + 1) + ST(i, j)) - vm * (ST(i, j) + ST(i, j - 1)));
+      hyadv = hdxom1 * (vp * (STL(0, j + 1) + STL(0, j)) - vm * (STL(0, j) + STL(0, j - 1)));
     }
     double rhs = -(hxadv + hyadv);
     // ---- diffusion, src/omlsubs.F:733-759 ----
@@ -184,9 +254,9 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
     else rhs = rhs + P.d2tfac * dc - P.d4tfac * (d[-DW] + dw + de + d[DW] - 4.0 * dc);
     // ---- oml, src/omlsubs.F:101-128 ----
     const long o = (long)(j - 1) * ldt + (i - 1);
-    const double sm = P.sstm[o], wk = P.wekto[o];
+    const double sm = sM[(ly + 2) * MW + (lx0 + 2)], wk = e_wk[r];
     const double diabat = 0.5 * wk * (sm + P.toc1);
-    double sstnew = sm + P.tdto * (rhs + P.hmoinv * (P.rrcpoc * P.fnet[o] + diabat));
+    double sstnew = sm + P.tdto * (rhs + P.hmoinv * (P.rrcpoc * e_fnet[r] + diabat));
     const double xfoent = -(0.5 * P.dtoinv) * wk * (sm - P.toc1);
     const double dtonew = P.toc1 - sstnew;
     const double coneno = P.entfac * fmax(0.0, dtonew);
@@ -202,7 +272,7 @@ __global__ __launch_bounds__(OML_NT) void k_oml_step(const QgOmlParams P) {
 #undef PO1
 #undef TXo
 #undef TYo
-#undef ST
+#undef STL
 #undef UF
 #undef VF
   const int b = blockIdx.y * gridDim.x + blockIdx.x;

@@ -1503,7 +1503,7 @@ extern "C" int qgcm_hip_oml_init(qgcm_hip_handle c, const qgcm_hip_oml_params *p
   if (!o.sst[0]) {
     o.ldt = round_up(nxt, 16);
     const size_t nT = (size_t)o.ldt * nyt, nP = (size_t)g.ldx * g.ny;
-    o.nblkA = ((nxt + OML_TX - 1) / OML_TX) * ((nyt + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+    o.nblkA = ((nxt + OML_TX - 1) / OML_TX) * ((nyt + OML_SH - 1) / OML_SH);
     o.nblkB = ((g.nx + OML_TX - 1) / OML_TX) * ((g.ny + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
     struct { double **ptr; size_t n; } bufs[] = {{&o.sst[0], nT}, {&o.sst[1], nT}, {&o.sst[2], nT}, {&o.fnet, nT}, {&o.wekto, nT},
                                                  {&o.xfo, nT}, {&o.taux, nP}, {&o.tauy, nP}, {&o.partA, (size_t)3 * o.nblkA},
@@ -1582,7 +1582,7 @@ static void fill_oml_params(qgcm_hip_ctx *c, QgOmlParams &P) {
   P.po1 = c->p[c->ip]; P.taux = o.taux; P.tauy = o.tauy;
   P.entoc = c->entoc;
   P.partA = o.partA; P.partB = o.partB;
-  P.nblkA = ((P.nxt + OML_TX - 1) / OML_TX) * ((P.jT1 - P.jX0 + 1 + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+  P.nblkA = ((P.nxt + OML_TX - 1) / OML_TX) * ((P.jT1 - P.jX0 + 1 + OML_SH - 1) / OML_SH);
   P.nblkB = ((P.nx + OML_TX - 1) / OML_TX) * ((P.jP1 - P.jP0 + 1 + OML_TY * OML_RPT * OML_ERR - 1) / (OML_TY * OML_RPT * OML_ERR));
   P.sc = c->sc; P.diag = o.diag;
   const double dxom2 = 1.0 / (pr.dxo * pr.dxo), rdxof0 = 1.0 / (pr.dxo * pr.fnot); // src/q-gcm.F:435
@@ -1603,7 +1603,7 @@ static void fill_oml_params(qgcm_hip_ctx *c, QgOmlParams &P) {
 static int launch_oml_a(qgcm_hip_ctx *c, double *send3) {
   QgOmlParams P;
   fill_oml_params(c, P);
-  dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.jT1 - P.jX0 + 1 + OML_TY * OML_RPT - 1) / (OML_TY * OML_RPT));
+  dim3 gA((P.nxt + OML_TX - 1) / OML_TX, (P.jT1 - P.jX0 + 1 + OML_SH - 1) / OML_SH);
   hipLaunchKernelGGL(k_oml_step, gA, dim3(OML_NT), 0, c->stream, P);
   if (send3) hipLaunchKernelGGL(k_oml_sum3, dim3(1), dim3(OML_NT), 0, c->stream, (const double *)P.partA, P.nblkA, send3);
   HIPCHECK(hipGetLastError());
