@@ -354,6 +354,15 @@ class HipSlab:
         check(self.L.qgcm_hip_get_scalars(self.h, _dp(s)))
         return s
 
+    def set_sponge(self, r_spl, c1_spl):
+        """The fork's sponge layer on this slab: the GLOBAL ramp r_spl(nxpo, nypo), of which the local rows (incl. halo
+        rows) are sent; None switches the term off."""
+        if r_spl is None:
+            check(self.L.qgcm_hip_set_sponge(self.h, None, 0.0))
+            return
+        loc = np.asfortranarray(np.asarray(r_spl, dtype=np.float64)[:, self.joff:self.joff + self.nyl])
+        check(self.L.qgcm_hip_set_sponge(self.h, _dp(loc), float(c1_spl)))
+
     def get_monitors(self):
         """(ermaso, emfroc) of the last constraint solve of a zonally cyclic slab (every rank holds the same numbers)."""
         e, f = np.zeros(self.cfg.nlo - 1), np.zeros(self.cfg.nlo - 1)

@@ -97,8 +97,8 @@ def test_slab_handles_refuse_whole_domain_entry_points():
             check(sl.L.qgcm_hip_steps(sl.h, 1, 1))
         with pytest.raises(QgcmHipError, match="whole domain"):
             check(sl.L.qgcm_hip_valids(sl.h, None, None))
-        with pytest.raises(QgcmHipError, match="stage must be 1..5"):
-            sl.stage(6)
+        with pytest.raises(QgcmHipError, match="stage must be 1..7"):
+            sl.stage(8)
     finally:
         sl.close()
     # the split tendency launch (stages 4 / 5) needs three 16-row tile rows: a 20-row slab refuses

@@ -1057,6 +1057,35 @@ def test_wide_tendency_tiles_are_bit_exact(name, monkeypatch):
         m.close()
 
 
+def test_sponge_layer_on_y_slabs():
+    """The sponge term (src/qgosubs.F:203-205) on the y-slab path: every slab takes its rows of the ramp
+    (qgcm_hip_set_sponge on a slab handle); two slabs of the box_tiny_spl reference fixture against the reference itself."""
+    import torch
+    from qgcm_hip import hostinit
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset("box_tiny_spl")
+    g = load_golden("box_tiny_spl")
+    consts = global_consts(cfg)
+    slabs = [HipSlab(cfg, consts, g0, g1, r, 2, sync_each_call=True) for r, (g0, g1) in enumerate(partition(cfg.nypo, 2))]
+    try:
+        so = SlabOcean(cfg, slabs, LocalComm(2, after=torch.cuda.synchronize))
+        so.homsol()
+        for sl in slabs:
+            sl.set_sponge(g["in_rspl"], float(g["in_c1spl"]))
+        so.scatter_state(g["init_po"], g["init_pom"], g["init_qo"], g["init_qom"], g["in_wekpo"], g["in_entoc"], g["in_xon"], g["init_scal"])
+        so.steps(26, s0=1)
+        got = [np.zeros((cfg.nxpo, cfg.nypo, cfg.nlo)) for _ in range(4)]
+        for g0, g1, fields in so.gather_local():
+            for dst, src in zip(got, fields):
+                dst[:, g0 - 1:g1, :] = src
+        for f, x in zip(FIELDS, got):
+            assert relerr(x, g["steps26_" + f]) < TOL_60, f
+        assert relerr(got[0], load_golden("box_tiny")["steps26_po"]) > 1e-4   # (the term is not a no-op in this fixture)
+    finally:
+        for sl in slabs:
+            sl.close()
+
+
 def test_natl5_long_run_within_the_references_own_thread_spread():
     """SURVEY 8(d)'s long-run tolerances at BASELINE's full size (NAtl 5 km, 961 x 961 x 3, configs[1]): after 160
     ocean steps <= 1e-9, after 1600 (ten model days) <= 1e-7 of the field's max-norm, against samples of the REFERENCE
