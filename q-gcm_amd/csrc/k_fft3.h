@@ -149,8 +149,11 @@ struct Fft3Plan {
   // every thread, and the few beyond NT go to the first lanes of wave 1 in stage 1, wave 2 in stage 2, wave 3 in
   // stage 3 - so no SIMD carries a second wave's worth of work in every stage (a 320-thread workgroup puts two of its
   // five waves on one SIMD: measured VALU-bound on exactly that SIMD).
+  // (a stage with more than NT + 64 butterflies - the cheap radix of an uneven plan, e.g. 12 of 12 * 20 * 20 - gives
+  //  the second round to the first lanes of the workgroup: item NT + tid)
   template <int NT>
   static __device__ __forceinline__ int extra_item(int tid, int wave, int items) {
+    if (items > NT + 64) return NT + tid < items ? NT + tid : -1;
     const int e = NT + tid - 64 * wave;
     return (tid >= 64 * wave && e < items) ? e : -1;
   }
@@ -160,7 +163,7 @@ struct Fft3Plan {
   template <int NT>
   static __device__ __forceinline__ Tw prefetch(const double2 *__restrict__ twid, int tid) {
     static_assert(NT % 64 == 0 && NT >= 256, "whole waves; the extra butterflies go to waves 1 .. 3");
-    static_assert(R2 * R3 <= NT + 64 && R1 * R3 <= NT + 64 && R1 * R2 <= NT + 64, "at most one extra butterfly per lane");
+    static_assert(R2 * R3 <= 2 * NT && R1 * R3 <= 2 * NT && R1 * R2 <= 2 * NT, "at most one extra butterfly per lane");
     Tw t;
     const int e1 = extra_item<NT>(tid, 1, R2 * R3), e2 = extra_item<NT>(tid, 2, R1 * R3);
     t.w1 = twid[tid < R2 * R3 ? tid : 0];

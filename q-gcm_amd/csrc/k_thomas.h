@@ -359,7 +359,9 @@ struct QgThomasCorr {
   const int *poff, *qoff;
 };
 #define THC_NT 256
+#ifndef THC_UNR
 #define THC_UNR 4 // rows in flight per thread and trip of the correction loop
+#endif
 #define THC_PER ((TH_MSG + TH_CST) * TH_KW) // doubles per rank and block: summaries + constants of 16 wavenumbers
 #define THC_LDS (THC_PER + TH_KW + 1)       // ... + the inflow per wavenumber (+ 1: bank spread between ranks)
 __global__ __launch_bounds__(THC_NT) void k_thomas_corr(const QgThomasParams P, const QgThomasCorr T) {
@@ -412,10 +414,25 @@ __global__ __launch_bounds__(THC_NT) void k_thomas_corr(const QgThomasParams P, 
   {
     const long mk0 = TH_MSG * ((long)m * ldw + bx * TH_KW), ck0 = TH_CST * ((long)m * ldw + bx * TH_KW);
     const long cstride = (long)TH_CST * P.g.nl * ldw;
-    for (int it = tid; it < P.nranks * THC_PER; it += THC_NT) {
-      const int sr = it / THC_PER, jj = it - sr * THC_PER;
-      sG[sr * THC_LDS + jj] = jj < TH_MSG * TH_KW ? P.gath[(long)sr * P.gath_stride + mk0 + jj]
-                                                  : P.cgath[(long)sr * cstride + ck0 + (jj - TH_MSG * TH_KW)];
+    // (four loads in flight per trip: a rolled loop waits for every load before it requests the next - with eight ranks
+    //  that was four memory round trips one after the other in every workgroup's latency chain, now one)
+    const int total = P.nranks * THC_PER;
+    for (int it0 = tid; it0 < total; it0 += 4 * THC_NT) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = it0 + u * THC_NT, itc = it < total ? it : 0;
+        const int sr = itc / THC_PER, jj = itc - sr * THC_PER;
+        v[u] = jj < TH_MSG * TH_KW ? P.gath[(long)sr * P.gath_stride + mk0 + jj] : P.cgath[(long)sr * cstride + ck0 + (jj - TH_MSG * TH_KW)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int it = it0 + u * THC_NT;
+        if (it < total) {
+          const int sr = it / THC_PER, jj = it - sr * THC_PER;
+          sG[sr * THC_LDS + jj] = v[u];
+        }
+      }
     }
   }
   __syncthreads();
