@@ -20,7 +20,12 @@
 #ifndef FFT3_NT
 #define FFT3_NT 256
 #endif
+// (4800 = 12 * 20 * 20: the cheap radix takes the stage with two rounds of butterflies - profiles/r4_fft_plan_4800.log)
+#ifdef FFT3_4800_OLD // (A/B: the round-2 plan of the 4800-point rows)
 #define QG_FFT3_PLANS(X) X(1, 15, 16, 20) X(2, 16, 16, 18) X(3, 16, 16, 16) X(4, 12, 15, 16)
+#else
+#define QG_FFT3_PLANS(X) X(1, 12, 20, 20) X(2, 16, 16, 18) X(3, 16, 16, 16) X(4, 12, 15, 16)
+#endif
 #include "k_dst64.h"
 #include "k_thomas.h"
 #include "k_misc.h"
