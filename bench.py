@@ -185,6 +185,71 @@ def coupled_figure(cfg, po, wek, device, nocean=400):
             "state_finite": ok, "note": "forcing held; ocean and atmosphere on their own HIP streams of one GPU"}
 
 
+def natl1_one_slab_figure(device, nranks=8, nrep=12):
+    """BASELINE configs[4] on ONE GPU: NAtl 1 km (4801 x 4801 x 3, dto = 180 s) cut into the eight y-slabs of the 8-GPU
+    run; after real steps of all eight (virtual ranks on this GPU, the exchange buffers then hold consistent values) ONE
+    middle slab steps alone - what one GPU of the eight computes per step, the two exchanges not included.  Four steps as
+    one captured graph, HIP events, the state restored before every replay (a slab whose neighbours stand still leaves
+    the real solution after 5-6 steps).  The 8-GPU figure derived from it is a PREDICTION and labelled so."""
+    import torch
+    from qgcm_hip import hostinit, preset, synth
+    from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
+    cfg = preset("natl1")
+    consts = global_consts(cfg)
+    po = synth.gaussian_eddy(cfg)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    qo = hostinit.q_from_p(cfg, consts["amatoc"], consts["yporel"], consts["ddynoc"], po)
+    scal = hostinit.constr(cfg, consts["amatoc"], po, po)
+    slabs = [HipSlab(cfg, consts, g0, g1, r, nranks, device=device, sync_each_call=True) for r, (g0, g1) in enumerate(partition(cfg.nypo, nranks))]
+    try:
+        so = SlabOcean(cfg, slabs, LocalComm(nranks, after=torch.cuda.synchronize))
+        so.homsol()
+        so.scatter_state(po, po, qo, qo, wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1), scal)
+        del po, qo, wek
+        so.steps(4, s0=1)
+        torch.cuda.synchronize()
+        r = nranks // 2
+        x = slabs[r]
+        x.sync_each_call = False
+        st = torch.cuda.ExternalStream(x.stream_ptr)
+        mine = so.th_gath[r][r * x.th_len:(r + 1) * x.th_len]
+        state0, scal0 = x.get_state(), x.get_scalars()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            for _ in range(4):     # the stages of SlabOcean.step for this slab alone (steps without an averaging)
+                x.stage(1, so.th_send[r])
+                mine.copy_(so.th_send[r])   # its own summary is current, the other ranks' stay at the last real step
+                x.stage(2, so.th_gath[r], so.h_to_lo[r], so.h_to_hi[r])
+                x.stage(3, so.h_from_lo[r], so.h_from_hi[r], None, 0)
+        e0, e1, tg = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), 0.0
+        for _ in range(nrep):
+            x.set_state(*state0)
+            x.set_scalars(scal0)
+            with torch.cuda.stream(st):
+                e0.record()
+                gr.replay()
+                e1.record()
+            e1.synchronize()
+            tg += e0.elapsed_time(e1)
+        us = 1e3 * tg / (4 * nrep)
+        fin = bool(all(np.isfinite(f).all() for f in x.get_state()))
+        npts = cfg.nxpo * (x.g1 - x.g0 + 1)
+        return {"us_per_step_one_slab_alone": round(us, 2), "slab_rows": x.g1 - x.g0 + 1, "grid": [cfg.nxpo, cfg.nypo, cfg.nlo],
+                "n_slabs": nranks, "state_finite": fin,
+                "step_hbm_frac_of_8TBps": round(56 * npts * 8.0 / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "measured": "one middle slab of the eight stepping alone on this GPU, four steps as one captured graph, "
+                            "%d replays, HIP events; no collective in the window" % nrep,
+                "PREDICTED_8_gpu_steps_per_s": round(1e6 / (us + 37.0), 1),
+                "prediction_assumes": "two exchanges per step on the critical path, not measured here: all-gather of the slab "
+                                      "summaries 25 us + halo send/recv 12 us (DESIGN 6b')"}
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        for sl in slabs:
+            sl.close()
+
+
 def pmc_traffic(kernel, name="pmc_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary, if any."""
     path = os.path.join(ROOT, "profiles", name)
@@ -790,6 +855,13 @@ def main():
             out["coupled"] = coupled_figure(cfg, po, wek, local_rank)
         except Exception as e:  # noqa: BLE001 - secondary figure only
             out["coupled"] = {"error": repr(e)}
+        # Secondary figure: BASELINE configs[4] (NAtl 1 km over 8 GPUs) as far as ONE GPU can measure it
+        try:
+            if not secondary:
+                raise RuntimeError("skipped (QGCM_BENCH_NO_SECONDARY=1)")
+            out["natl1km_one_slab_of_8"] = natl1_one_slab_figure(local_rank)
+        except Exception as e:  # noqa: BLE001 - secondary figure only
+            out["natl1km_one_slab_of_8"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             model.close()
             out["cpu_baseline"] = cpu_baseline(cfg, po, wek)
