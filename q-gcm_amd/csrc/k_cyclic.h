@@ -355,6 +355,22 @@ __global__ __launch_bounds__(256) void k_unpack_cyc(const QgUnpackParams P, cons
   for (int k = 0; k < NL; ++k) qg_pair_store_wt(P.pnew + P.g.fstride * k + o, pl[k], valid); // (qgcm_dev.h)
   if (!valid) return;
   const int G = gj + joff;
+  // y-slab halo messages (k_halo_pack's layout, k_misc.h), written here when the host passes the buffers (slab
+  // stage 2); an edge row with a neighbour is never a zonal boundary row, so its q is what k_tend set
+  if (BDY && P.msg_lo && gj - P.g.jlo < 3) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) P.msg_lo[((long)k * 3 + (gj - P.g.jlo)) * P.g.ldx + (gi - 1)] = pl[k];
+    if (gj == P.g.jlo)
+#pragma unroll
+      for (int k = 0; k < NL; ++k) P.msg_lo[((long)NL * 3 + k) * P.g.ldx + (gi - 1)] = B.qo[P.g.fstride * k + o];
+  }
+  if (BDY && P.msg_hi && P.g.jhi - gj < 3) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) P.msg_hi[((long)k * 3 + (gj - (P.g.jhi - 2))) * P.g.ldx + (gi - 1)] = pl[k];
+    if (gj == P.g.jhi)
+#pragma unroll
+      for (int k = 0; k < NL; ++k) P.msg_hi[((long)NL * 3 + k) * P.g.ldx + (gi - 1)] = B.qo[P.g.fstride * k + o];
+  }
   if (BDY && (G == 1 || G == nyg)) {
     double pin[NL];
     point(G == 1 ? gj + 1 : gj - 1, pin);

@@ -247,9 +247,28 @@ __global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P, cons
 #pragma unroll
   for (int k = 0; k < NL; ++k) qg_pair_store_wt(P.pnew + P.g.fstride * k + o, pl[k], valid); // (qgcm_dev.h)
   if (!valid) return;
+  // y-slab halo messages (k_halo_pack's layout), written here when the host passes the buffers (slab stage 2): the
+  // first / last three owned rows of the new pressure, and below the edge row of q
+  const bool qlo = BDY && P.msg_lo && gj == P.g.jlo, qhi = BDY && P.msg_hi && gj == P.g.jhi;
+  if (BDY && P.msg_lo && gj - P.g.jlo < 3) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) P.msg_lo[((long)k * 3 + (gj - P.g.jlo)) * P.g.ldx + (gi - 1)] = pl[k];
+  }
+  if (BDY && P.msg_hi && P.g.jhi - gj < 3) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) P.msg_hi[((long)k * 3 + (gj - (P.g.jhi - 2))) * P.g.ldx + (gi - 1)] = pl[k];
+  }
   if (BDY) {
     const bool ns = (G == 1 || G == nyg);
     const bool we = (gi == 1 || gi == nx);
+    if ((qlo || qhi) && !(ns || we)) { // interior columns of the q row: set by k_tend
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        const double q = B.qo[P.g.fstride * k + o];
+        if (qlo) P.msg_lo[((long)NL * 3 + k) * P.g.ldx + (gi - 1)] = q;
+        if (qhi) P.msg_hi[((long)NL * 3 + k) * P.g.ldx + (gi - 1)] = q;
+      }
+    }
     if (ns || we) {
       const int ii = ns ? gi : (gi == 1 ? 2 : nx - 1);
       const int jj = ns ? (G == 1 ? gj + 1 : gj - 1) : gj;
@@ -265,6 +284,8 @@ __global__ __launch_bounds__(256) void k_unpack_box(const QgUnpackParams P, cons
         double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
         if (k == NL - 1) q = q + B.ddynoc[o];
         B.qo[P.g.fstride * k + o] = q;
+        if (qlo) P.msg_lo[((long)NL * 3 + k) * P.g.ldx + (gi - 1)] = q;
+        if (qhi) P.msg_hi[((long)NL * 3 + k) * P.g.ldx + (gi - 1)] = q;
       }
     }
   }

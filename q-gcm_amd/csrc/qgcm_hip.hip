@@ -1198,7 +1198,7 @@ static void fill_constr_params(qgcm_hip_ctx *c, QgConstrParams &P) {
 
 static void fill_bdy_params(qgcm_hip_ctx *c, QgBdyParams &P);
 
-static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
+static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nullptr, double *msg_hi = nullptr) {
   const QgGeom &g = c->g;
   QgUnpackParams P;
   memset(&P, 0, sizeof(P));
@@ -1209,6 +1209,9 @@ static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy) {
   P.sc = c->sc;
   P.pch1 = c->pch1; P.pch2 = c->pch2; P.pbh = c->pbh;
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  if ((msg_lo || msg_hi) && (!fuse_bdy || g.jhi - g.jlo + 1 < 3)) QG_FAIL("k_unpack: halo messages need the fused boundary PV and three owned rows");
+  P.msg_lo = msg_lo; // y-slab halo messages written by the same threads (slab stage 2)
+  P.msg_hi = msg_hi;
   QgBdyParams B;
   fill_bdy_params(c, B); // B.qo = current qo; B.po unused by the fused kernel
   dim3 grid((g.nx + 255) / 256, g.jhi - g.jlo + 1);
@@ -2328,8 +2331,9 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
         if (qgcm_hip_constr(c)) return 1;
         if (qgcm_hip_row_transform(c, 1)) return 1;
       }
-      if (qgcm_hip_unpack(c, 1)) return 1;
-      if (nranks > 1 && qgcm_hip_halo_pack(c, b, cc)) return 1;
+      // the unpack launch also writes the halo messages (first / last three owned rows of po, edge row of qo)
+      if (check_ready(c, "qgcm_hip_slab_stage") || launch_unpack(c, true, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr)) return 1;
+      c->ip ^= 1;
       return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);
     case 3:
       if (nranks > 1 && qgcm_hip_halo_unpack(c, a, b)) return 1;
