@@ -9,7 +9,7 @@ import glob
 import json
 import sys
 
-NAMES = [("k_tend", "k_tend"), ("k_thomas_corr", "k_thomas_corr"), ("k_oml_step", "k_oml_step"), ("k_oml_entoc", "k_oml_entoc"), ("k_dst64_unpack", "k_dst_inv"), ("k_dst64<", "k_dst_fwd"), ("k_dst_box", "k_dst_fwd"),
+NAMES = [("k_tend", "k_tend"), ("k_rfft3_unpack", "k_rfft3_unpack"), ("k_thomas_corr", "k_thomas_corr"), ("k_oml_step", "k_oml_step"), ("k_oml_entoc", "k_oml_entoc"), ("k_dst64_unpack", "k_dst_inv"), ("k_dst64<", "k_dst_fwd"), ("k_dst_box", "k_dst_fwd"),
          ("k_rfft_cyc<true", "k_dst_inv"), ("k_rfft_cyc<false", "k_dst_fwd"),
          ("k_thomas", "k_thomas"), ("k_unpack", "k_unpack"), ("k_constr", "k_constr"), ("k_lf_average", "k_lf_average"),
          ("k_copy", "k_copy_1GiB_calibration")]

@@ -139,7 +139,7 @@ struct Fft3Plan {
   // rows of R3 are padded by one (stage 3: a thread owns a contiguous row), blocks of R2 rows by one more (the
   // post-processing reads X[k], k consecutive = consecutive k1 = consecutive blocks: without it every lane of a wave
   // hit the same LDS banks)
-  static constexpr int N = R1 * R2 * R3, PITCH = R3 + 1, BLOCK = R2 * PITCH + 1, LDS_CPLX = R1 * BLOCK;
+  static constexpr int N = R1 * R2 * R3, PITCH = R3 + 1, BLOCK = R2 * PITCH + 1, LDS_CPLX = R1 * BLOCK, R1R2 = R1 * R2;
   static __device__ __forceinline__ int pos_in(int n) { return (n / (R2 * R3)) * BLOCK + (n % (R2 * R3)) + (n % (R2 * R3)) / R3; }
   static __device__ __forceinline__ int pos_out(int k) { return (k % R1) * BLOCK + ((k / R1) % R2) * PITCH + k / (R1 * R2); }
   // The two twiddle bases of a thread (W_N^r for its stage-1 butterfly, W_N^(R1*n3) for its stage-2 butterfly) are

@@ -31,6 +31,7 @@
 #include "k_misc.h"
 #include "k_cyclic.h"
 #include "k_rfft64.h"
+#include "k_fft3_unpack.h"
 #include "k_oml.h"
 #include "k_valids.h"
 #include "k_setup.h"
@@ -558,6 +559,7 @@ extern "C" int qgcm_hip_set_grid(qgcm_hip_handle c, const double *yporel, const 
       HIPCHECK(hipFuncSetAttribute((const void *)k_dst_box<false, FFT3_NT, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
       HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<false, PL, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
       HIPCHECK(hipFuncSetAttribute((const void *)k_rfft_cyc<true, PL, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
+      HIPCHECK(hipFuncSetAttribute((const void *)k_rfft3_unpack<PL, 3, FFT3_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->fft3_lds)); \
     }
     QG_FFT3_PLANS(QG_FFT3_SETUP)
 #undef QG_FFT3_SETUP
@@ -1285,6 +1287,55 @@ static int launch_rfft_unpack(qgcm_hip_ctx *c, bool fuse_bdy, bool constr) {
   return 0;
 }
 
+// long rows (three-stage plans): inverse rows + homogeneous corrections + modes -> layers + boundary PV in one launch
+// that reads the solved modes once (k_fft3_unpack.h); nlo = 3, the boundary PV always fused
+static bool can_fuse_fft3_unpack(const qgcm_hip_ctx *c) {
+  return c->fft3 && !c->force_generic_dst && !c->no_fused_unpack && c->g.nl == 3 && c->g.ldx % 2 == 0 && c->g.cyc;
+}
+
+static int launch_fft3_unpack(qgcm_hip_ctx *c, bool own_constr, double *msg_lo = nullptr, double *msg_hi = nullptr) {
+  const QgGeom &g = c->g;
+  if (!can_fuse_fft3_unpack(c)) QG_FAIL("k_fft3_unpack: not a long-row configuration of three layers");
+  if ((msg_lo || msg_hi) && g.jhi - g.jlo + 1 < 3) QG_FAIL("k_fft3_unpack: halo messages need three owned rows");
+  QgDstParams D;
+  memset(&D, 0, sizeof(D));
+  D.g = g;
+  D.wrk = c->wrk;
+  D.twid = c->twid;
+  D.sintab = c->sintab;
+  D.N = c->fftN;
+  D.nlayers = g.nl;
+  QgUnpackParams P;
+  memset(&P, 0, sizeof(P));
+  P.g = g;
+  P.wrk = c->wrk;
+  P.ochom = c->ochom;
+  P.pnew = c->p[c->ip ^ 1];
+  P.sc = c->sc;
+  P.pch1 = c->pch1; P.pch2 = c->pch2; P.pbh = c->pbh;
+  P.msg_lo = msg_lo;
+  P.msg_hi = msg_hi;
+  for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  QgBdyParams B;
+  fill_bdy_params(c, B);
+  const int npairs = (g.jr1 - g.jr0 + 2) / 2;
+  dim3 grid(8 * ((npairs + 7) / 8) * g.nl);
+  KTimer t(c, KN_DSTI);
+  if (g.cyc) {
+    QgCycConstrParams Q;
+    fill_cyc_constr_params(c, Q);
+#define QG_FFT3U_LAUNCH(ID, R1, R2, R3)                                                                                   \
+    if (c->fft3 == ID) {                                                                                                  \
+      typedef Fft3Plan<R1, R2, R3> PL;                                                                                    \
+      hipLaunchKernelGGL((k_rfft3_unpack<PL, 3, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, c->stream, D, P, B, Q, own_constr ? 1 : 0); \
+    }
+    QG_FFT3_PLANS(QG_FFT3U_LAUNCH)
+#undef QG_FFT3U_LAUNCH
+  }
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
 // box fast path: inverse row transform + modes -> layers (+ boundary PV) in one launch (k_dst64_unpack)
 static bool can_fuse_dst_unpack(const qgcm_hip_ctx *c) {
   return !c->g.cyc && !c->force_generic_dst && !c->no_fused_unpack && (c->fftN == 64 * 15 || c->fftN == 64 * 3) &&
@@ -1426,6 +1477,11 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
     // cyclic ocean with generic row sizes (SOcn 5 km), inside qgcm_hip_steps: part A of the constraint algebra rides in
     // the Thomas launch, part B in the inverse-row launch (it reads ksum and ybnd, not wrk): no launch of its own
     if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, true)) return 1;
+    if (fuse_bdy && can_fuse_fft3_unpack(c)) { // long rows: one launch, every workgroup evaluates part B for itself
+      if (launch_fft3_unpack(c, true)) return 1;
+      c->ip ^= 1;
+      return 0;
+    }
     if (launch_dst(c, c->wrk, c->g.nl, true, 0, nullptr, true)) return 1;
     if (launch_unpack(c, fuse_bdy)) return 1;
     c->ip ^= 1;
@@ -2322,6 +2378,12 @@ extern "C" int qgcm_hip_slab_stage(qgcm_hip_handle c, int stage, double *a, doub
         if (!fused_constr && qgcm_hip_constr(c)) return 1; // area integrals of the whole basin came with the slab summaries
         // the fused kernel also writes the halo messages (first / last three owned rows of po, edge row of qo)
         if (launch_dst_unpack(c, true, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr, fused_constr)) return 1;
+        c->ip ^= 1;
+        return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);
+      }
+      if (can_fuse_fft3_unpack(c)) { // long rows: inverse rows + unpack + halo messages in one launch (k_fft3_unpack.h)
+        if (qgcm_hip_constr(c)) return 1;
+        if (launch_fft3_unpack(c, false, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr)) return 1;
         c->ip ^= 1;
         return oml_halo_pack(c, nranks > 1 ? b : nullptr, nranks > 1 ? cc : nullptr);
       }

@@ -211,6 +211,8 @@ PRESETS = {
     # nxto = 192 = 64*3 and 960 = 64*15: exercise the wave-per-row-pair real-FFT kernels (k_rfft64.h) of the cyclic path
     "cyc_med": OceanConfig("cyc_med", 12, 10, 12, 4, 16, 3, dxo=2.5e4, dta=240.0, ah4oc=(1.2e10,) * 3, **_SOCN),
     "cyc_960": OceanConfig("cyc_960", 60, 12, 60, 3, 16, 3, dxo=5.0e3, **_SOCN),
+    # long rows with a three-stage plan (nxto = 2880 = 12 * 15 * 16) on few rows: the fused inverse rows + unpack launch
+    "cyc_2880": OceanConfig("cyc_2880", 180, 12, 180, 3, 16, 3, dxo=5.0e3, **_SOCN),
     # examples/double_gyre_ocean_only: parameters_data.F.dg_oo + input.params.dg_oo (BASELINE configs[0], [1])
     "natl5": OceanConfig("natl5", 384, 96, 60, 60, 16, 3, dxo=5.0e3, **_NATL),
     # examples/southern_ocean_ocean_only (BASELINE configs[2])

@@ -564,6 +564,37 @@ def test_fused_inverse_transform_unpack_bitwise():
         ms.close()
 
 
+def test_fused_long_row_unpack_vs_two_launches():
+    """k_rfft3_unpack (long rows of a cyclic ocean: inverse rows + homogeneous corrections + modes -> layers + zonal
+    boundary PV in one launch that mixes the modes BEFORE the transform) against k_rfft_cyc<true> + k_unpack_cyc: the
+    same linear algebra in another order, so equal to rounding - through qgcm_hip_steps (30 steps, one averaging)."""
+    import os
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("cyc_2880")
+    mf = OceanModel(cfg)
+    os.environ["QGCM_HIP_NO_FUSED_UNPACK"] = "1"
+    try:
+        ms = OceanModel(cfg)
+    finally:
+        del os.environ["QGCM_HIP_NO_FUSED_UNPACK"]
+    try:
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        for mod in (mf, ms):
+            mod.set_p(po, 0.99 * po)
+            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+            mod.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
+            mod.steps(30, s0=1)
+        for f, x, y in zip(FIELDS, mf.get_state(), ms.get_state()):
+            assert relerr(x, y) < 1e-12, f
+        sf, ss = mf.get_scalars(), ms.get_scalars()
+        assert np.abs(sf - ss).max() <= 1e-12 * np.abs(ss).max()
+    finally:
+        mf.close()
+        ms.close()
+
+
 @pytest.mark.parametrize("name,nranks", [("box_small", 1), ("box_small", 2), ("box_med", 3), ("box_med", 4)])
 def test_y_slab_decomposition_on_one_gpu(name, nranks):
     """The multi-GPU path with all slabs as virtual ranks on this one GPU: the slab
@@ -610,7 +641,7 @@ def test_y_slab_decomposition_on_one_gpu(name, nranks):
         o.close()
 
 
-@pytest.mark.parametrize("name,nranks", [("cyc_small", 1), ("cyc_small", 2), ("cyc_med", 3), ("cyc_960", 4)])
+@pytest.mark.parametrize("name,nranks", [("cyc_small", 1), ("cyc_small", 2), ("cyc_med", 3), ("cyc_960", 4), ("cyc_2880", 3)])
 def test_cyclic_y_slab_decomposition_on_one_gpu(name, nranks):
     """Zonally cyclic ocean on y-slabs (virtual ranks on this one GPU): the boundary line sums of the momentum
     constraints ride in the step message (rank 0 owns the southern, the last rank the northern boundary), the
