@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define QGCM_HIP_MAXL 8 /* max number of QG layers supported (nlo <= 8) */
+#define QGCM_HIP_MAXL 8 /* max number of QG layers supported: 2 <= nlo <= 8 (kernels instantiated for every count;
+                           the fused single-launch forms of the inversion for nlo <= 4) */
 /* 2: qgcm_hip_params.atmos + the atmosphere entry points
  * 3: qgcm_hip_get_monitors (required by the Fortran shim), qgcm_hip_prepare_steps, qgcm_hip_stream_mix_bandwidth,
  *    qgcm_hip_set_sponge; halo rows of qgcm_hip_slab_steps default to neighbour send/recv */

@@ -24,6 +24,9 @@ CONFIGS = {
     "box_tiny": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0),
     "box_small": (12, 10, 6, 5, 16, 3, "9.37456D-05", "1.75360D-11", 0),
     "box_tiny2": (8, 8, 5, 4, 6, 2, "5.92D-05", "2.08D-11", 0),
+    # more layers than the examples carry (nlo is a compile-time PARAMETER of the reference, src/parameters_data.F:41,54)
+    "box_tiny5": (8, 8, 4, 3, 12, 5, "9.37456D-05", "1.75360D-11", 0),
+    "cyc_tiny6": (4, 8, "nxta", 3, 12, 6, "-1.19467D-04", "1.31301D-11", 1),
     # box_tiny compiled with the specified-temperature southern boundary of the mixed layer (-Dsb_hflux,
     # as examples/double_gyre_coupled; src/omlsubs.F:405-422)
     "box_tiny_sb": (8, 8, 4, 3, 12, 3, "9.37456D-05", "1.75360D-11", 0, "-Dsb_hflux"),

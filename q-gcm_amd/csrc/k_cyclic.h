@@ -127,17 +127,24 @@ template <int NL>
 __device__ __forceinline__ void constr_cyc_partA(const QgCycConstrParams &P, int lane, double *ocsnew, double *ocnnew) {
   // boundary line sums of the previous qgostep: lane (5*(2k+side) + v) adds the BSUM_NB block
   // partials of quantity v in block order (src/qgosubs.F:150-163, 279-297, 404-443)
-  double bs = 0.0;
-  if (lane < 10 * NL) {
-    const int ks = lane / 5, v = lane % 5;
-    const double *src = (ks & 1) ? P.bpart_n : P.bpart;
-    for (int blk = 0; blk < BSUM_NB; ++blk) bs += src[((long)ks * BSUM_NB + blk) * 5 + v];
+  // (10 NL sums on 64 lanes: a second round for seven and eight layers)
+  constexpr int NR = (10 * NL + 63) / 64;
+  double bs[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    bs[r] = 0.0;
+    const int idx = lane + 64 * r;
+    if (idx < 10 * NL) {
+      const int ks = idx / 5, v = idx % 5;
+      const double *src = (ks & 1) ? P.bpart_n : P.bpart;
+      for (int blk = 0; blk < BSUM_NB; ++blk) bs[r] += src[((long)ks * BSUM_NB + blk) * 5 + v];
+    }
   }
   double bq[2 * NL][5];
 #pragma unroll
   for (int ks = 0; ks < 2 * NL; ++ks)
 #pragma unroll
-    for (int v = 0; v < 5; ++v) bq[ks][v] = __shfl(bs, 5 * ks + v);
+    for (int v = 0; v < 5; ++v) bq[ks][v] = __shfl(bs[(5 * ks + v) / 64], (5 * ks + v) % 64);
   QgScalars *sc = P.sc;
   const double fnot = P.fnot, tdto = P.tdto;
   const double entfac = 0.5 * P.dyo * fnot * fnot;

@@ -22,21 +22,22 @@ __device__ __forceinline__ bool fft3u_block(int id, int nl, int nrp, int &rp, in
   return rp < nrp;
 }
 
-// boundary PV of layer kl on a zonal boundary row (src/vorsubs.F:245-388, atqzbd :470 as written): pl = the row's
-// pressure in every layer (constants of the row here), pin = the inward neighbour's pressure in layer kl
+// boundary PV of layer kl on a zonal boundary row of the ocean (src/vorsubs.F:245-388): pl = the row's pressure in every
+// layer (constants of the row here), pin = the inward neighbour's pressure in layer kl
 template <int NL>
-__device__ __forceinline__ double fft3u_bdy_q(const QgBdyParams &B, int kl, const double *pl, double pin, double by, bool atm_south) {
+__device__ __forceinline__ double fft3u_bdy_q(const QgBdyParams &B, int kl, const double *pl, double pin, double by) {
   double ap = 0.0, plk = 0.0; // (0.0 + x is x: the terms add up in the order l = kl - 1, kl, kl + 1 of the reference)
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     if (l == kl) plk = pl[l];
-    if (l >= kl - 1 && l <= kl + 1) ap = ap + B.f0A[kl + NL * l] * ((atm_south && l == kl) ? pin : pl[l]);
+    if (l >= kl - 1 && l <= kl + 1) ap = ap + B.f0A[kl + NL * l] * pl[l];
   }
   return B.bcfaco_f0 * (pin - plk) - ap + by;
 }
 
 // ---------------------------------------------------------------------------
-// zonally cyclic ocean: half-complex spectral rows -> layer pressures (k_rfft_cyc<true> + k_unpack_cyc<.., true>)
+// zonally cyclic ocean: half-complex spectral rows -> layer pressures (k_rfft_cyc<true> + k_unpack_cyc<.., true>);
+// not for the atmospheric channel (its rows are short: k_rfft64_unpack)
 // grid: 8 * ceil(row pairs / 8) * NL workgroups of NT threads; dynamic LDS as k_rfft_cyc
 // own_constr: part B of the constraint algebra (c1, c2, c3 from the zonal-mean column, k_cyclic.h) is evaluated by
 // every workgroup for itself and recorded by the first; 0: read from the scalars (y-slabs: k_constr_cyc ran before)
@@ -155,9 +156,8 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
       hNk = hN[l];
     }
   }
-  const bool topo = kl == (D.g.atm ? 0 : NL - 1); // topography term: ocean bottom layer nlo, atmosphere layer 1
+  const bool topo = kl == NL - 1; // topography term: bottom layer nlo
   const double byS = doS ? B.beta * B.yporel[jS - 1] : 0.0, byN = doN ? B.beta * B.yporel[jN - 1] : 0.0;
-  const bool atmS = D.g.atm && kl == NL - 1;
   // halo messages (k_halo_pack's layout): p rows gj - jlo < 3 / jhi - gj < 3, q row gj == jlo / jhi (set by k_tend)
   auto msg_p = [&](int gj, int col, double v) {
     if (U.msg_lo && gj - jlo < 3) U.msg_lo[((long)kl * 3 + (gj - jlo)) * ldx + col] = v;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
   auto bdy_col = [&](bool south, int col, double pin) {
     const int jb = south ? jS : jN;
     const long o = (long)(jb - 1) * ldx + col;
-    double q = fft3u_bdy_q<NL>(B, kl, south ? hS : hN, pin, south ? byS : byN, south && atmS);
+    double q = fft3u_bdy_q<NL>(B, kl, south ? hS : hN, pin, south ? byS : byN);
     if (topo) q = q + B.ddynoc[o];
     B.qo[fs * kl + o] = q;
   };

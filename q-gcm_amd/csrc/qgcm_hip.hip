@@ -37,6 +37,21 @@
 #include "k_setup.h"
 #include "slab_comm.h"
 
+// kernels that are templates on the number of layers: instantiated for nlo = 2 .. QGCM_HIP_MAXL (8); the fused fast
+// paths (k_dst64_unpack, k_rfft64_unpack, k_rfft3_unpack, the riding constraint solves) stay with nlo <= 4
+static_assert(QG_MAXL == 8, "QG_SWITCH_NL lists the cases");
+#define QG_SWITCH_NL(nl, X, what)                    \
+  switch (nl) {                                      \
+    case 2: X(2); break;                             \
+    case 3: X(3); break;                             \
+    case 4: X(4); break;                             \
+    case 5: X(5); break;                             \
+    case 6: X(6); break;                             \
+    case 7: X(7); break;                             \
+    case 8: X(8); break;                             \
+    default: QG_FAIL(what ": unsupported nlo");      \
+  }
+
 static thread_local char g_err[512] = "";
 
 #define QG_FAIL(...)                             \
@@ -211,7 +226,6 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
   *h = nullptr;
   if (prm->nlo < 2 || prm->nlo > QG_MAXL) QG_FAIL("qgcm_hip_create: nlo=%d outside 2..%d", prm->nlo, QG_MAXL);
   if (prm->nxpo < 4 || prm->nypo < 4) QG_FAIL("qgcm_hip_create: grid too small");
-  if (prm->nlo > 4) QG_FAIL("qgcm_hip_create: kernels are instantiated for nlo = 2, 3, 4");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) QG_FAIL("qgcm_hip_create: no HIP device (%s) - there is no CPU fallback", hipGetErrorString(e));
@@ -939,6 +953,10 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
     case 2: QG_TEND(2); break;
     case 3: QG_TEND(3); break;
     case 4: QG_TEND(4); break;
+    case 5: QG_TEND(5); break;
+    case 6: QG_TEND(6); break;
+    case 7: QG_TEND(7); break;
+    case 8: QG_TEND(8); break;
     default: QG_FAIL("k_tend: unsupported nlo");
   }
 #undef QG_TEND
@@ -975,7 +993,7 @@ static int launch_dst(qgcm_hip_ctx *c, double *wrk, int nlayers, bool inverse, i
   dim3 grid(npairs, nlayers);
   dim3 grid64((npairs + D64_WAVES - 1) / D64_WAVES, nlayers);
   if (cyc_part_b) { // generic cyclic inverse rows: one extra workgroup runs part B of the constraint algebra
-    if (!inverse || !g.cyc || !c->d_cycq) QG_FAIL("launch_dst: part B rides in the inverse rows of a cyclic ocean with homogeneous solutions");
+    if (!inverse || !g.cyc || !c->d_cycq || g.nl > 4) QG_FAIL("launch_dst: part B rides in the inverse rows of a cyclic ocean with homogeneous solutions, nlo <= 4");
     P.cycq = c->d_cycq;
     grid.x += 1;
   }
@@ -1081,7 +1099,7 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
   // zonally cyclic geometries use the CYCA instantiation for the whole-column solve: it fills ybnd, and its extra
   // workgroup runs part A of the constraint algebra when asked to (inside qgcm_hip_steps)
   const bool cyca = (phase == 0 && g.cyc);
-  if (cyc_part_a && (phase != 0 || !c->d_cycq)) QG_FAIL("k_thomas: part A of the constraint algebra needs the homogeneous solutions");
+  if (cyc_part_a && (phase != 0 || !c->d_cycq || g.nl > 4)) QG_FAIL("k_thomas: part A of the constraint algebra needs the homogeneous solutions and nlo <= 4");
   if (cyca) P.cycq = cyc_part_a ? c->d_cycq : nullptr; // (its extra workgroup is added to the grid below)
   KTimer t(c, KN_THOMAS, st);
 #define QG_TH(RV, KWV)                                                                                                  \
@@ -1132,6 +1150,10 @@ static int launch_constr(qgcm_hip_ctx *c) {
       case 2: hipLaunchKernelGGL((k_constr_cyc<2>), dim3(1), dim3(64), 0, c->stream, Q); break;
       case 3: hipLaunchKernelGGL((k_constr_cyc<3>), dim3(1), dim3(64), 0, c->stream, Q); break;
       case 4: hipLaunchKernelGGL((k_constr_cyc<4>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      case 5: hipLaunchKernelGGL((k_constr_cyc<5>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      case 6: hipLaunchKernelGGL((k_constr_cyc<6>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      case 7: hipLaunchKernelGGL((k_constr_cyc<7>), dim3(1), dim3(64), 0, c->stream, Q); break;
+      case 8: hipLaunchKernelGGL((k_constr_cyc<8>), dim3(1), dim3(64), 0, c->stream, Q); break;
       default: QG_FAIL("k_constr_cyc: unsupported nlo");
     }
     HIPCHECK(hipGetLastError());
@@ -1142,6 +1164,10 @@ static int launch_constr(qgcm_hip_ctx *c) {
     case 2: hipLaunchKernelGGL((k_constr_box<2>), dim3(1), dim3(64), 0, c->stream, P); break;
     case 3: hipLaunchKernelGGL((k_constr_box<3>), dim3(1), dim3(64), 0, c->stream, P); break;
     case 4: hipLaunchKernelGGL((k_constr_box<4>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 5: hipLaunchKernelGGL((k_constr_box<5>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 6: hipLaunchKernelGGL((k_constr_box<6>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 7: hipLaunchKernelGGL((k_constr_box<7>), dim3(1), dim3(64), 0, c->stream, P); break;
+    case 8: hipLaunchKernelGGL((k_constr_box<8>), dim3(1), dim3(64), 0, c->stream, P); break;
     default: QG_FAIL("k_constr: unsupported nlo");
   }
   HIPCHECK(hipGetLastError());
@@ -1227,6 +1253,10 @@ static int launch_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nullpt
     case 2: QG_UNPACK(2); break;
     case 3: QG_UNPACK(3); break;
     case 4: QG_UNPACK(4); break;
+    case 5: QG_UNPACK(5); break;
+    case 6: QG_UNPACK(6); break;
+    case 7: QG_UNPACK(7); break;
+    case 8: QG_UNPACK(8); break;
     default: QG_FAIL("k_unpack: unsupported nlo");
   }
 #undef QG_UNPACK
@@ -1290,7 +1320,7 @@ static int launch_rfft_unpack(qgcm_hip_ctx *c, bool fuse_bdy, bool constr) {
 // long rows (three-stage plans): inverse rows + homogeneous corrections + modes -> layers + boundary PV in one launch
 // that reads the solved modes once (k_fft3_unpack.h); nlo = 3, the boundary PV always fused
 static bool can_fuse_fft3_unpack(const qgcm_hip_ctx *c) {
-  return c->fft3 && !c->force_generic_dst && !c->no_fused_unpack && c->g.nl == 3 && c->g.ldx % 2 == 0 && c->g.cyc;
+  return c->fft3 && !c->force_generic_dst && !c->no_fused_unpack && c->g.nl == 3 && c->g.ldx % 2 == 0 && c->g.cyc && !c->g.atm;
 }
 
 static int launch_fft3_unpack(qgcm_hip_ctx *c, bool own_constr, double *msg_lo = nullptr, double *msg_hi = nullptr) {
@@ -1473,7 +1503,7 @@ static int ocinvq_impl(qgcm_hip_ctx *c, bool fuse_bdy, bool in_step = false) {
   // (the wave-per-row-pair kernels of k_rfft64.h have no such extra workgroup: they are fused with the unpack step
   //  above unless that is switched off, and then keep the stand-alone constraint launch)
   const bool generic_rows = c->force_generic_dst || !(c->fftN == 64 * 3 || c->fftN == 64 * 6 || c->fftN == 64 * 15);
-  if (c->g.cyc && in_step && !c->no_fused_constr && generic_rows) {
+  if (c->g.cyc && in_step && !c->no_fused_constr && generic_rows && c->g.nl <= 4) { // (the riding parts A / B: nlo <= 4)
     // cyclic ocean with generic row sizes (SOcn 5 km), inside qgcm_hip_steps: part A of the constraint algebra rides in
     // the Thomas launch, part B in the inverse-row launch (it reads ksum and ybnd, not wrk): no launch of its own
     if (launch_thomas(c, c->wrk, c->tt, c->g.nl, 0, nullptr, nullptr, 0, 1, 0, nullptr, true)) return 1;
@@ -1760,7 +1790,7 @@ extern "C" int qgcm_hip_valids(qgcm_hip_handle c, double *out, int *solnok) {
   if (check_ready(c, "qgcm_hip_valids")) return 1;
   if (!c->whole) QG_FAIL("qgcm_hip_valids: only for a handle that owns the whole domain");
   const QgGeom &g = c->g;
-  if (g.nl < 2 || g.nl > 4) QG_FAIL("qgcm_hip_valids: unsupported nlo");
+  if (g.nl < 2 || g.nl > QG_MAXL) QG_FAIL("qgcm_hip_valids: unsupported nlo");
   const int nres = 2 * VAL_NMM + g.nl + 1;
   if (!c->val_part) {
     if (dalloc(&c->val_part, (size_t)(2 * VAL_NMM + QG_MAXL) * VAL_NB)) return 1;
@@ -1782,20 +1812,11 @@ extern "C" int qgcm_hip_valids(qgcm_hip_handle c, double *out, int *solnok) {
   P.part = c->val_part;
   P.out = c->val_out;
   P.ocnorm = 1.0 / ((double)g.nxt * (double)(g.ny - 1));
-  switch (g.nl) {
-    case 2:
-      hipLaunchKernelGGL((k_valids_scan<2>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);
-      hipLaunchKernelGGL((k_valids_final<2>), dim3(1), dim3(VAL_NT), 0, c->stream, P);
-      break;
-    case 3:
-      hipLaunchKernelGGL((k_valids_scan<3>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);
-      hipLaunchKernelGGL((k_valids_final<3>), dim3(1), dim3(VAL_NT), 0, c->stream, P);
-      break;
-    default:
-      hipLaunchKernelGGL((k_valids_scan<4>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);
-      hipLaunchKernelGGL((k_valids_final<4>), dim3(1), dim3(VAL_NT), 0, c->stream, P);
-      break;
-  }
+#define QG_VALIDS(NLV)                                                                       \
+  hipLaunchKernelGGL((k_valids_scan<NLV>), dim3(VAL_NB), dim3(VAL_NT), 0, c->stream, P);      \
+  hipLaunchKernelGGL((k_valids_final<NLV>), dim3(1), dim3(VAL_NT), 0, c->stream, P)
+  QG_SWITCH_NL(g.nl, QG_VALIDS, "k_valids");
+#undef QG_VALIDS
   HIPCHECK(hipGetLastError());
   double h[2 * VAL_NMM + QG_MAXL + 1];
   HIPCHECK(hipMemcpyAsync(h, c->val_out, sizeof(double) * nres, hipMemcpyDeviceToHost, c->stream));
@@ -1819,20 +1840,11 @@ static int launch_area_sums(qgcm_hip_ctx *c) {
   P.g = g;
   P.f[0] = c->p[c->ip]; P.f[1] = c->p[c->ip ^ 1]; P.f[2] = c->q[c->iq];
   P.part = c->area_part; P.out = c->area_out;
-  switch (g.nl) {
-    case 2:
-      hipLaunchKernelGGL((k_area_partial<2>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);
-      hipLaunchKernelGGL((k_area_final<2>), dim3(1), dim3(64), 0, c->stream, P);
-      break;
-    case 3:
-      hipLaunchKernelGGL((k_area_partial<3>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);
-      hipLaunchKernelGGL((k_area_final<3>), dim3(1), dim3(64), 0, c->stream, P);
-      break;
-    default:
-      hipLaunchKernelGGL((k_area_partial<4>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);
-      hipLaunchKernelGGL((k_area_final<4>), dim3(1), dim3(64), 0, c->stream, P);
-      break;
-  }
+#define QG_AREA(NLV)                                                                          \
+  hipLaunchKernelGGL((k_area_partial<NLV>), dim3(AREA_NB), dim3(AREA_NT), 0, c->stream, P);     \
+  hipLaunchKernelGGL((k_area_final<NLV>), dim3(1), dim3(64), 0, c->stream, P)
+  QG_SWITCH_NL(g.nl, QG_AREA, "k_area");
+#undef QG_AREA
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -1851,11 +1863,9 @@ extern "C" int qgcm_hip_init_from_p(qgcm_hip_handle c) {
     P.po = c->p[c->ip]; P.pom = c->p[c->ip ^ 1]; P.area = c->area_out; P.sc = c->sc;
     P.dxo = pr.dxo; P.dyo = pr.dyo; P.fnot = pr.fnot;
     for (int i = 0; i < g.nl * g.nl; ++i) P.amat[i] = pr.amatoc[i];
-    switch (g.nl) {
-      case 2: hipLaunchKernelGGL((k_constr_init<2>), dim3(1), dim3(64), 0, c->stream, P); break;
-      case 3: hipLaunchKernelGGL((k_constr_init<3>), dim3(1), dim3(64), 0, c->stream, P); break;
-      default: hipLaunchKernelGGL((k_constr_init<4>), dim3(1), dim3(64), 0, c->stream, P); break;
-    }
+#define QG_CINIT(NLV) hipLaunchKernelGGL((k_constr_init<NLV>), dim3(1), dim3(64), 0, c->stream, P)
+    QG_SWITCH_NL(g.nl, QG_CINIT, "k_constr_init");
+#undef QG_CINIT
     HIPCHECK(hipGetLastError());
   }
   // qcomp, ocqbdy / atqzbd, merqcy for both time levels: src/q-gcm.F:719-731, 738-749
@@ -2235,11 +2245,9 @@ extern "C" int qgcm_hip_area_integrals(qgcm_hip_handle c, double *xin) {
   if (c->g.cyc) QG_FAIL("qgcm_hip_area_integrals: box ocean only (spectral area integrals of the sine series)");
   QgConstrParams P;
   fill_constr_params(c, P);
-  switch (c->g.nl) {
-    case 2: hipLaunchKernelGGL((k_xin_only<2>), dim3(1), dim3(64), 0, c->stream, P); break;
-    case 3: hipLaunchKernelGGL((k_xin_only<3>), dim3(1), dim3(64), 0, c->stream, P); break;
-    default: hipLaunchKernelGGL((k_xin_only<4>), dim3(1), dim3(64), 0, c->stream, P); break;
-  }
+#define QG_XIN(NLV) hipLaunchKernelGGL((k_xin_only<NLV>), dim3(1), dim3(64), 0, c->stream, P)
+  QG_SWITCH_NL(c->g.nl, QG_XIN, "k_xin_only");
+#undef QG_XIN
   HIPCHECK(hipGetLastError());
   return qgcm_hip_get_inv_diag(c, xin, nullptr);
 }

@@ -189,6 +189,11 @@ PRESETS = {
     "box_tiny2": OceanConfig("box_tiny2", 8, 8, 5, 4, 6, 2, fnot=5.92e-05, beta=2.08e-11, cyclic=False,
                              dxo=1.0e5, dta=720.0, ah2oc=(0.0, 0.0), ah4oc=(3.2e12, 3.2e12),
                              hoc=(500.0, 3500.0), gpoc=(0.02,)),
+    # five and six layers (the kernels are templates on nlo = 2 .. 8; own reference builds box_tiny5 / cyc_tiny6)
+    "box_tiny5": OceanConfig("box_tiny5", 8, 8, 4, 3, 12, 5, dxo=1.0e5, dta=720.0, ah2oc=(0.0,) * 5, ah4oc=(3.2e12,) * 5,
+                             hoc=(300.0, 400.0, 600.0, 1000.0, 1700.0), gpoc=(0.02, 0.012, 0.008, 0.005), **_NATL),
+    "cyc_tiny6": OceanConfig("cyc_tiny6", 4, 8, 4, 3, 12, 6, dxo=1.0e5, dta=720.0, ah2oc=(0.0,) * 6, ah4oc=(3.2e12,) * 6,
+                             hoc=(250.0, 350.0, 500.0, 700.0, 1000.0, 1200.0), gpoc=(0.02, 0.015, 0.01, 0.007, 0.004), **_SOCN),
     # ... and compiled with -Dsponge_layer_k247 (src/qgosubs.F:203-205): own reference builds box_tiny_spl / cyc_tiny_spl
     "box_tiny_spl": OceanConfig("box_tiny_spl", 8, 8, 4, 3, 12, 3, dxo=1.0e5, dta=720.0,
                                 ah4oc=(3.2e12,) * 3, c1_spl=-2.5e-5, l_spl=4.0e5, **_NATL),

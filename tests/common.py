@@ -67,9 +67,9 @@ def scal_err(model, g, tag, cfg):
 # ap3soc / ap3noc boundary sums) - tests/golden/make_golden.py
 # *_spl: the tiny grids of reference builds with -Dsponge_layer_k247 (src/qgosubs.F:203-205)
 CONFIG_NAMES = ("box_tiny", "box_tiny2", "box_small", "cyc_tiny", "cyc_small", "box_tiny_ah2", "cyc_tiny_ah2",
-                "box_tiny_spl", "cyc_tiny_spl")
-BOX_NAMES = ("box_tiny", "box_tiny2", "box_small", "box_tiny_ah2", "box_tiny_spl")
-SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_small": (1, 30),
+                "box_tiny_spl", "cyc_tiny_spl", "box_tiny5", "cyc_tiny6")
+BOX_NAMES = ("box_tiny", "box_tiny2", "box_small", "box_tiny_ah2", "box_tiny_spl", "box_tiny5")
+SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_tiny5": (1, 2, 26), "cyc_tiny6": (1, 2, 26), "box_small": (1, 30),
          "cyc_tiny": (1, 2, 25, 26, 60), "cyc_small": (1, 30), "box_tiny_ah2": (1, 2, 26), "cyc_tiny_ah2": (1, 2, 26),
          "box_tiny_spl": (1, 2, 26), "cyc_tiny_spl": (1, 2, 26)}
 

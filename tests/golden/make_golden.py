@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "q-gcm_amd", "python"))
 import ref_binding  # noqa: E402
 from qgcm_hip import config, synth  # noqa: E402
 
-SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_small": (1, 30),
+SNAPS = {"box_tiny": (1, 2, 25, 26, 60), "box_tiny2": (1, 26), "box_tiny5": (1, 2, 26), "cyc_tiny6": (1, 2, 26), "box_small": (1, 30),
          "cyc_tiny": (1, 2, 25, 26, 60), "cyc_small": (1, 30),
          "box_tiny_ah2": (1, 2, 26), "cyc_tiny_ah2": (1, 2, 26),
          "box_tiny_spl": (1, 2, 26), "cyc_tiny_spl": (1, 2, 26)}

