@@ -156,7 +156,7 @@ def coupled_figure(cfg, po, wek, device, nocean=400):
     """double_gyre_coupled (BASELINE configs[3]): ocean steps/s of the coupled main loop (1 ocean + nstr atmospheric
     steps per ocean step, src/q-gcm.F:1220-1268) and the atmosphere's own step time."""
     import torch
-    from qgcm_hip import AtmosModel, OceanModel, atmos_of, coupled_steps, synth
+    from qgcm_hip import AtmosModel, OceanModel, atmos_of, coupled_steps, share_gpu, synth
     at = atmos_of(cfg)
     f = synth.atmos_fields(at)
     a = AtmosModel(at, ddynat=f["ddynat"], device=device)
@@ -169,20 +169,27 @@ def coupled_figure(cfg, po, wek, device, nocean=400):
     a.steps(200, s0=1)                      # atmosphere alone: graphs of both averaging phases instantiated
     ms_a = a.time_steps(1200, s0=201)
     nt = 1401
-    coupled_steps(o, a, nt, 100 * nstr, nstr)   # warm-up of the coupled loop (instantiates the ocean's graphs)
-    nt += 100 * nstr
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    coupled_steps(o, a, nt, nocean * nstr, nstr)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def timed(nt):
+        coupled_steps(o, a, nt, 100 * nstr, nstr)   # warm-up of the coupled loop (instantiates the graphs of both halves)
+        nt += 100 * nstr
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        coupled_steps(o, a, nt, nocean * nstr, nstr)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, nt + nocean * nstr
+    dt_u, nt = timed(nt)                    # both halves on unrestricted streams: they queue for the same wave slots
+    acu = share_gpu(o, a)                   # disjoint CU ranges (qgcm_hip_set_cu_range): each half keeps its own pace
+    dt, nt = timed(nt)
     ok = bool(np.isfinite(a.get_state()[0]).all() and np.isfinite(o.get_state()[0]).all())
     a.close()
     o.close()
     return {"ocean_steps_per_s": round(nocean / dt, 2), "ms_per_ocean_step": round(1e3 * dt / nocean, 5),
             "atmos_steps_per_ocean_step": nstr, "atmos_alone_us_per_step": round(1e3 * ms_a / 1200, 3),
             "atmos_grid": [at.nxpa, at.nypa, at.nla], "model_years_per_day": round(cfg.model_years_per_day(nocean / dt), 1),
-            "state_finite": ok, "note": "forcing held; ocean and atmosphere on their own HIP streams of one GPU"}
+            "cu_partition": {"atmosphere_cus": acu, "ocean_steps_per_s_without_it": round(nocean / dt_u, 2)},
+            "state_finite": ok, "note": "forcing held; ocean and atmosphere on their own HIP streams of one GPU, each on its own "
+                                        "range of compute units (qgcm_hip_set_cu_range)"}
 
 
 def natl1_one_slab_figure(device, nranks=8, nrep=12):

@@ -42,7 +42,7 @@ extern "C" {
                            the fused single-launch forms of the inversion for nlo <= 4) */
 /* 2: qgcm_hip_params.atmos + the atmosphere entry points
  * 3: qgcm_hip_get_monitors (required by the Fortran shim), qgcm_hip_prepare_steps, qgcm_hip_stream_mix_bandwidth,
- *    qgcm_hip_set_sponge; halo rows of qgcm_hip_slab_steps default to neighbour send/recv */
+ *    qgcm_hip_set_sponge, qgcm_hip_set_cu_range; halo rows of qgcm_hip_slab_steps default to neighbour send/recv */
 #define QGCM_HIP_ABI_VERSION 3
 
 typedef struct qgcm_hip_ctx *qgcm_hip_handle;
@@ -184,6 +184,12 @@ int qgcm_hip_get_bsums(qgcm_hip_handle h, double *b);
  * mod(nt,nstr) == 1 (src/q-gcm.F:1220-1268), each with its own averaging rule.  The two handles run on
  * their own HIP streams, so the small atmospheric kernels overlap the ocean's. Either handle may be NULL. */
 int qgcm_hip_coupled_steps(qgcm_hip_handle oc, qgcm_hip_handle atm, int nt0, int n, int nstr);
+/* Two handles that step side by side on one GPU (the ocean and the atmosphere under qgcm_hip_coupled_steps) can be
+ * given disjoint ranges of compute units: the handle's HIP stream is replaced by one that may use the CUs
+ * first .. first+count-1 only (count = 0: all of them again).  Without it the atmosphere's small dependent launches
+ * queue behind the ocean's chip-filling ones.  Not for handles with a communicator.  Synchronous; no reference
+ * counterpart (the reference runs both halves on the same OpenMP threads, src/q-gcm.F:1220-1268). */
+int qgcm_hip_set_cu_range(qgcm_hip_handle h, int first, int count);
 
 /* Helmholtz solve for homsol: wrk(nxpo,nypo) in/out, boc(nxto)
  * (replaces hsbxoc / hscyoc, src/ocisubs.F:415-618). Synchronous. */

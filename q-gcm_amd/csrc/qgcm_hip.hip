@@ -123,6 +123,7 @@ struct qgcm_hip_ctx {
   size_t fft3_lds = 0;
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
+  int cu_first = 0, cu_count = 0; // qgcm_hip_set_cu_range: the CUs this handle's stream may use (0: all)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
   bool tend_wide;         // QGCM_HIP_TEND_WIDE=1: the tendency kernel's HBM-bound instantiation (32-wide tiles, plain stores) at any size (tests)
   std::vector<double> bd2oc;
@@ -2118,6 +2119,38 @@ extern "C" int qgcm_hip_get_bsums(qgcm_hip_handle c, double *b) {
 // The ocean steps of the window are queued on the ocean handle's stream and the atmospheric steps on the
 // atmosphere's: with the forcing frozen the two halves do not exchange data inside the window, so the streams need
 // no cross dependencies and the GPU overlaps the atmosphere's small kernels with the ocean's.
+// Two handles that step side by side on one GPU (qgcm_hip_coupled_steps: the ocean and the atmosphere of a coupled run)
+// queue for the same wave slots: the atmosphere's twelve small dependent launches per ocean step then advance only as
+// slots of the ocean's chip-filling launches retire (107 us per ocean step at NAtl 5 km, where the ocean alone takes 68
+// and the atmosphere's three steps alone 67).  Given disjoint CU ranges (hipExtStreamCreateWithCUMask) each half keeps
+// its own pace: 94.6 us with 96 CUs for the atmosphere and 160 for the ocean (profiles/r4_coupled_cu_masks.log).
+// The handle's stream is REPLACED (not a second stream beside it: the runtime multiplexes streams onto few hardware
+// queues, and masked streams that share one ran four times slower); count = 0 gives the unrestricted stream back.
+extern "C" int qgcm_hip_set_cu_range(qgcm_hip_handle c, int first, int count) {
+  if (!c) QG_FAIL("qgcm_hip_set_cu_range: null handle");
+  if (c->sc_comm) QG_FAIL("qgcm_hip_set_cu_range: not for a handle with a communicator (its exchanges are ordered on the stream it has)");
+  int ncu = 0, dev = 0;
+  HIPCHECK(hipGetDevice(&dev));
+  HIPCHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  if (first < 0 || count < 0 || first + count > ncu || ncu > 1024) QG_FAIL("qgcm_hip_set_cu_range: CUs %d..%d outside 0..%d", first, first + count - 1, ncu - 1);
+  if (first == c->cu_first && count == c->cu_count) return 0;
+  HIPCHECK(hipStreamSynchronize(c->stream));
+  drop_graphs(c); // (executable graphs are uploaded to the stream they replay on)
+  hipStream_t ns = nullptr;
+  if (count > 0) {
+    uint32_t mask[32];
+    memset(mask, 0, sizeof(mask));
+    for (int i = first; i < first + count; ++i) mask[i / 32] |= 1u << (i % 32);
+    HIPCHECK(hipExtStreamCreateWithCUMask(&ns, (uint32_t)((ncu + 31) / 32), mask));
+  } else
+    HIPCHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+  HIPCHECK(hipStreamDestroy(c->stream));
+  c->stream = ns;
+  c->cu_first = first;
+  c->cu_count = count;
+  return 0;
+}
+
 extern "C" int qgcm_hip_coupled_steps(qgcm_hip_handle oc, qgcm_hip_handle atm, int nt0, int n, int nstr) {
   if (nt0 < 1 || n < 0 || nstr < 1) QG_FAIL("qgcm_hip_coupled_steps: bad step range");
   if (oc && check_ready(oc, "qgcm_hip_coupled_steps")) return 1;

@@ -10,5 +10,5 @@ library or without a HIP device raises.
 """
 from .config import AtmosConfig, OceanConfig, OmlConfig, PRESETS, atmos_of, atmos_preset, oml_preset, preset  # noqa: F401
 from .lib import QgcmHipError, check, load_library, library_path  # noqa: F401
-from .model import AtmosModel, OceanModel, coupled_steps  # noqa: F401
+from .model import AtmosModel, OceanModel, coupled_steps, share_gpu  # noqa: F401
 from . import hostinit, synth  # noqa: F401

@@ -49,7 +49,7 @@ SYMBOLS = [
     "qgcm_hip_set_scalars", "qgcm_hip_get_scalars", "qgcm_hip_get_inv_diag", "qgcm_hip_get_monitors",
     "qgcm_hip_qgostep", "qgcm_hip_ocinvq", "qgcm_hip_ocqbdy", "qgcm_hip_lf_average", "qgcm_hip_ocqbdy_host",
     "qgcm_hip_steps", "qgcm_hip_sync", "qgcm_hip_helmholtz",
-    "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps",
+    "qgcm_hip_qgastep", "qgcm_hip_atinvq", "qgcm_hip_atqzbd", "qgcm_hip_get_bsums", "qgcm_hip_coupled_steps", "qgcm_hip_set_cu_range",
     "qgcm_hip_wrk_fill", "qgcm_hip_wrk_get", "qgcm_hip_wrk_set", "qgcm_hip_area_integrals",
     "qgcm_hip_local_rows", "qgcm_hip_row_transform", "qgcm_hip_thomas_msg_len", "qgcm_hip_thomas_phase",
     "qgcm_hip_thomas_const_len", "qgcm_hip_thomas_consts", "qgcm_hip_set_thomas_consts",
@@ -102,6 +102,7 @@ def load_library():
         getattr(L, n).argtypes = [vp]
     L.qgcm_hip_get_bsums.argtypes = [vp, dp]
     L.qgcm_hip_coupled_steps.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.qgcm_hip_set_cu_range.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_ocqbdy_host.argtypes = [vp, dp, dp]
     L.qgcm_hip_steps.argtypes = [vp, C.c_int, C.c_int]
     L.qgcm_hip_helmholtz.argtypes = [vp, dp, dp]

@@ -232,12 +232,15 @@ def test_atmosphere_continuity_monitors_vs_reference():
             m.close()
 
 
-def test_coupled_main_loop_full_size_vs_reference_sample():
+@pytest.mark.parametrize("partition", [False, True])
+def test_coupled_main_loop_full_size_vs_reference_sample(partition):
     """BASELINE configs[3] at FULL size through qgcm_hip_coupled_steps: NAtl 5 km ocean (961 x 961 x 3) and the
     385 x 97 x 3 atmosphere on this GPU, forcing held, against samples of the coupled reference build itself after
-    nt = 9 (three ocean steps) and nt = 30 (ten) - tests/golden/make_golden_atmos.py coupled_fullsize."""
+    nt = 9 (three ocean steps) and nt = 30 (ten) - tests/golden/make_golden_atmos.py coupled_fullsize.  Second run: the
+    two handles on disjoint ranges of compute units (share_gpu -> qgcm_hip_set_cu_range), as bench.py's coupled figure
+    runs them: where a workgroup runs changes no result."""
     from common import cpl_fullsize_errs, cpl_fullsize_inputs
-    from qgcm_hip import AtmosModel, OceanModel, coupled_steps
+    from qgcm_hip import AtmosModel, OceanModel, coupled_steps, share_gpu
     g = load_golden("cpl_natl5_sample")
     oc, at = config.preset("cpl_natl5"), config.atmos_preset("cpl_natl5")
     po, pom, wekpo, f = cpl_fullsize_inputs(g, oc, at)
@@ -246,6 +249,8 @@ def test_coupled_main_loop_full_size_vs_reference_sample():
     o.set_p(po, pom)
     o.set_forcing(wekpo, np.zeros_like(wekpo), np.zeros(oc.nlo - 1))
     atm_apply(a, f)
+    if partition:
+        assert share_gpu(o, a) > 0
     done = 0
     for upto, tol in ((9, 1e-12), (30, 1e-11)):
         coupled_steps(o, a, done + 1, upto - done, int(g["nstr"]))
@@ -254,6 +259,36 @@ def test_coupled_main_loop_full_size_vs_reference_sample():
         assert all(v < tol for v in e.values()), (upto, e)
     o.close()
     a.close()
+
+
+def test_cu_range_arguments_and_bitwise_results():
+    """qgcm_hip_set_cu_range: bad ranges are refused; 30 steps on 64 of the CUs, and back on all of them, give the bits
+    of an unrestricted handle (graphs are rebuilt for the new stream)."""
+    import torch
+    from qgcm_hip import OceanModel, QgcmHipError, check, synth
+    cfg = config.preset("box_small")
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    m, r = OceanModel(cfg), OceanModel(cfg)
+    try:
+        for bad in ((-1, 8), (0, ncu + 1), (ncu - 4, 8), (0, -2)):
+            with pytest.raises(QgcmHipError, match="qgcm_hip_set_cu_range"):
+                check(m.L.qgcm_hip_set_cu_range(m.h, *bad))
+        po = synth.gaussian_eddy(cfg, noise=1e-2)
+        tx, ty = synth.wind_stress(cfg)
+        _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+        for mod in (m, r):
+            mod.set_p(po, 0.99 * po)
+            mod.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+        r.steps(60, s0=1)
+        check(m.L.qgcm_hip_set_cu_range(m.h, ncu // 4, ncu // 4))
+        m.steps(30, s0=1)
+        check(m.L.qgcm_hip_set_cu_range(m.h, 0, 0))
+        m.steps(30, s0=31)
+        for x, y in zip(m.get_state(), r.get_state()):
+            assert np.array_equal(x, y)
+    finally:
+        m.close()
+        r.close()
 
 
 def test_atmosphere_entry_points_reject_an_ocean_handle():
