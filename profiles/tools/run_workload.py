@@ -25,6 +25,9 @@ if what == "atmos":
     a = AtmosModel(at, ddynat=f["ddynat"])
     a.set_p(f["pa"], f["pam"])
     a.set_forcing(f["wekpa"], f["entat"], f["xan"], f["txis"], f["txin"], f["enis"], f["enin"])
+    if os.environ.get("ATM_CUS"):   # the atmosphere's share of a coupled run (qgcm_hip_set_cu_range)
+        from qgcm_hip.lib import check
+        check(a.L.qgcm_hip_set_cu_range(a.h, 0, int(os.environ["ATM_CUS"])))
     a.steps(200, s0=1)
     ms = a.time_steps(1000, s0=201)
     print("atmosphere 385x97x3: %.2f us per step (graph replay)" % (1e3 * ms / 1000))
