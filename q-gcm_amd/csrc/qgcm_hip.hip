@@ -1118,11 +1118,13 @@ static int launch_thomas(qgcm_hip_ctx *c, double *wrk, const QgThomasTab &tab, i
   }
   // 8 .. 16 rows per thread: 512-thread workgroups of 8 wavenumbers, two per CU (128 VGPRs), the pair that shares the
   // 128-byte lines of a 16-wavenumber block on ONE XCD (k_thomas.h; r3: NAtl 5 km 10.6 -> 9.9 us against 1024-thread
-  // workgroups); long columns (>= 20 rows per thread): 512 threads, 256 VGPRs; short ones: 1024 threads of 16 wavenumbers
+  // workgroups); long columns (>= 20 rows per thread): 512 threads, 256 VGPRs
   switch (c->thR) {
-    case 1: QG_TH(1, 16); break;
-    case 2: QG_TH(2, 16); break;
-    case 4: QG_TH(4, 16); break;
+    // (short columns too: 1024-thread workgroups of 16 wavenumbers measured slower everywhere - atmosphere 22.1 -> 21.3 us
+    //  per step, 27.9 -> 26.3 on the two XCDs of a coupled run: profiles/r4_coupled_cu_masks.log)
+    case 1: QG_TH(1, 8); break;
+    case 2: QG_TH(2, 8); break;
+    case 4: QG_TH(4, 8); break;
     case 8: QG_TH(8, 8); break;
     case 10: QG_TH(10, 8); break;
     case 12: QG_TH(12, 8); break;

@@ -386,11 +386,11 @@ class AtmosModel(OceanModel):
 
 def share_gpu(ocean, atmos, atmos_cus=None):
     """Give the two halves of a coupled run disjoint CU ranges of the GPU they share (qgcm_hip_set_cu_range): the
-    atmosphere the first atmos_cus compute units (default 3/8 of the device: 96 of an MI355X's 256), the ocean the rest;
+    atmosphere the first atmos_cus compute units (default 2/8 of the device: 64 of an MI355X's 256 = two XCDs), the ocean the rest;
     atmos_cus = 0 returns both to unrestricted streams.  Call before coupled_steps."""
     import torch
     ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    acu = (3 * ncu) // 8 if atmos_cus is None else int(atmos_cus)
+    acu = ncu // 4 if atmos_cus is None else int(atmos_cus)
     if acu == 0:
         check(ocean.L.qgcm_hip_set_cu_range(ocean.h, 0, 0))
         check(atmos.L.qgcm_hip_set_cu_range(atmos.h, 0, 0))
