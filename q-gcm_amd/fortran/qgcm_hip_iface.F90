@@ -154,6 +154,12 @@ module qgcm_hip_iface
       type(c_ptr), value :: oc, atm
       integer(c_int), value :: nt0, n, nstr
     end function
+    ! a handle's share of the GPU's compute units when two handles step side by side (qgcm_hip_coupled_steps)
+    integer(c_int) function qgcm_hip_set_cu_range(h, first, count) bind(C, name='qgcm_hip_set_cu_range')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: first, count
+    end function
     ! start-up / restart arithmetic and the progress sample on the device (src/q-gcm.F:711-731, 1933-2066;
     ! src/xfosubs.F:566-645)
     integer(c_int) function qgcm_hip_init_from_p(h) bind(C, name='qgcm_hip_init_from_p')
