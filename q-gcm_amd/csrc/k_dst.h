@@ -244,6 +244,32 @@ __global__ __launch_bounds__(NT, (PLAN::three_stage && NT == 384) ? 4 : 1) void 
   if (tid == 0) A[0] = {0.0, 0.0};
   const double *rbp = has_b ? rowb : rowa; // the odd last row has no partner: loads redirected, values zeroed
   const double bsc = has_b ? 1.0 : 0.0;
+  if constexpr (PLAN::three_stage) {
+    // compile-time length: a fixed number of rounds with a predicate instead of a loop whose trip count depends on the
+    // thread - every load of a thread is in flight at once (the rolled loop paid one memory round trip per few rounds)
+    constexpr int NS2 = (PLAN::N - 1) / 2, NIT = (NS2 + NT - 1) / NT;
+    double xa[NIT], xac[NIT], xb[NIT], xbc[NIT], sn[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int k = 1 + tid + it * NT, kc = k <= NS2 ? k : 1;
+      xa[it] = rowa[kc - 1];
+      xac[it] = rowa[n - kc];
+      xb[it] = rbp[kc - 1];
+      xbc[it] = rbp[n - kc];
+      sn[it] = P.sintab[kc];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int k = 1 + tid + it * NT;
+      if (k <= NS2) {
+        const double b0 = bsc * xb[it], b1 = bsc * xbc[it];
+        const double t1a = xa[it] - xac[it], t2a = sn[it] * (xa[it] + xac[it]);
+        const double t1b = b0 - b1, t2b = sn[it] * (b0 + b1);
+        A[PLAN::pos_in(k)] = {t1a + t2a, t1b + t2b};
+        A[PLAN::pos_in(N - k)] = {t2a - t1a, t2b - t1b};
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 1 + tid; k <= ns2; k += NT) {
     double xa = rowa[k - 1], xac = rowa[n - k];
@@ -253,6 +279,7 @@ __global__ __launch_bounds__(NT, (PLAN::three_stage && NT == 384) ? 4 : 1) void 
     double t1b = xb - xbc, t2b = sn * (xb + xbc);
     A[PLAN::pos_in(k)] = {t1a + t2a, t1b + t2b};
     A[PLAN::pos_in(N - k)] = {t2a - t1a, t2b - t1b};
+  }
   }
   if ((n & 1) && tid == 0) {
     int kc = ns2 + 1;
@@ -386,6 +413,7 @@ __global__ __launch_bounds__(NT, (PLAN::three_stage && NT == 384) ? 4 : 1) void 
     // elements 2t, 2t+1 as one 16-byte write-through store (qgcm_dev.h; N is even here, and element n = N - 1 of the
     // last pair is the padding column of the row): b[2t] = Z[t].y (Z[0].x for t = 0), b[2t+1] = Z[t+1].x, row b alike
     // from Z[N-t], Z[N-t-1]
+    // (the store loops stay loops: as rounds with a predicate they gained nothing here and lost 2 us per step at SOcn 5 km)
 #pragma unroll
     for (int t = tid; t < N / 2; t += NT) {
       const cplx za0 = Z[PLAN::pos_out(t)], za1 = Z[PLAN::pos_out(t + 1)];
@@ -571,6 +599,8 @@ __global__ __launch_bounds__(NT, (PLAN::three_stage && NT == 384) ? 4 : 1) void 
     // Xa_k = (Z_k + conj Z_{N-k})/2, Xb_k = (Z_k - conj Z_{N-k})/(2i)
     // half-complex order r(1) = X_0, r(2k) = Re X_k, r(2k+1) = Im X_k, r(N) = X_{N/2}: the 16-byte aligned pair
     // (2t, 2t+1) of the row is (Im X_t, Re X_{t+1}), (X_0, Re X_1) for t = 0 - one write-through store (qgcm_dev.h)
+    // (left as a loop over the thread's elements: fully unrolled - rounds with a predicate, as k_dst_box loads its rows -
+    //  the stores leave in one burst at the end and SOcn 5 km was 2 us per step SLOWER, profiles/r4_row_loops_ab.log)
 #pragma unroll
     for (int t = tid; t < (PLAN::three_stage ? NC / 2 : H); t += NT) {
       const cplx z1 = Z[PLAN::pos_out(t)], z2 = Z[PLAN::pos_out((N - t) % N)];
