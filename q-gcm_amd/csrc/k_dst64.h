@@ -703,15 +703,36 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
     const int gj = ja + r, G = gj + joff;
     const int wall = (G == 2) ? gj - 1 : (G == nyg - 1 ? gj + 1 : 0);
     if (!wall) continue;
-    for (int gi = tid + 1; gi <= nx; gi += NT) {
-      const long ow = (long)(wall - 1) * U.g.ldx + (gi - 1);
-      double pw[NL], pl[NL];
-      point(gi, wall, -1, nullptr, pw);
+    // A fixed number of rounds with a predicate, everything a round reads from global memory requested first: as a loop
+    // over gi (trip count depends on the thread: it stays rolled) this was one memory round trip per round, on the two
+    // workgroups that finish last anyway.
+    constexpr int NRW = (NX + NT - 1) / NT;
+    double ocw[NRW][NL - 1], oci[NRW][NL - 1], ddw[NRW];
 #pragma unroll
-      for (int k = 0; k < NL; ++k) U.pnew[fs * k + ow] = pw[k];
-      if (BDY) {
-        point(gi, gj, r, nullptr, pl);
-        bdy_q(ow, pw, pl, B.beta * B.yporel[wall - 1], B.ddynoc[ow], gi, wall);
+    for (int it = 0; it < NRW; ++it) {
+      const int gi = tid + 1 + it * NT, gic = gi <= nx ? gi : 1;
+      const long ow = (long)(wall - 1) * U.g.ldx + (gic - 1), oi = (long)(gj - 1) * U.g.ldx + (gic - 1);
+#pragma unroll
+      for (int m = 1; m < NL; ++m) {
+        ocw[it][m - 1] = U.ochom[fs * (m - 1) + ow];
+        oci[it][m - 1] = BDY ? U.ochom[fs * (m - 1) + oi] : 0.0;
+      }
+      ddw[it] = BDY ? B.ddynoc[ow] : 0.0;
+    }
+    const double byw = BDY ? B.beta * B.yporel[wall - 1] : 0.0;
+#pragma unroll
+    for (int it = 0; it < NRW; ++it) {
+      const int gi = tid + 1 + it * NT;
+      if (gi <= nx) {
+        const long ow = (long)(wall - 1) * U.g.ldx + (gi - 1);
+        double pw[NL], pl[NL];
+        point(gi, wall, -1, ocw[it], pw);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) U.pnew[fs * k + ow] = pw[k];
+        if (BDY) {
+          point(gi, gj, r, oci[it], pl);
+          bdy_q(ow, pw, pl, byw, ddw[it], gi, wall);
+        }
       }
     }
   }

@@ -297,7 +297,20 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_rfft64_unpack(
     // zonal boundary rows (1 and ny): done by the workgroup that holds the adjacent interior row
     const int wall = (gj == 2) ? 1 : (gj == ny - 1 ? ny : 0);
     if (!wall) continue;
-    for (int gi = tid + 1; gi <= nx; gi += NT) {
+    // (a fixed number of rounds with a predicate, the topography values of all rounds requested first: as a loop over gi -
+    //  trip count depends on the thread, it stays rolled - the two workgroups of the boundary rows paid one memory round
+    //  trip per round at the very end of the launch)
+    constexpr int NRW = (64 * M + 1 + NT - 1) / NT;
+    double ddw[NRW];
+#pragma unroll
+    for (int it = 0; it < NRW; ++it) {
+      const int gi = tid + 1 + it * NT;
+      ddw[it] = BDY ? B.ddynoc[(long)(wall - 1) * U.g.ldx + ((gi <= nx ? gi : 1) - 1)] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NRW; ++it) {
+      const int gi = tid + 1 + it * NT;
+      if (gi > nx) break;
       double pw[NL], pin[NL];
       point(gi, wall, -1, pw);
       const long ow = (long)(wall - 1) * U.g.ldx + (gi - 1);
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_rfft64_unpack(
           if (U.g.atm && k == NL - 1 && wall == 1) // southern value of the top layer: src/vorsubs.F:470 reads row 2
             ap = B.f0A[k + NL * (k - 1)] * pw[k - 1] + B.f0A[k + NL * k] * pin[k];
           double q = B.bcfaco_f0 * (pin[k] - pw[k]) - ap + by;
-          if (k == (U.g.atm ? 0 : NL - 1)) q = q + B.ddynoc[ow]; // topography: ocean layer nlo, atmosphere layer 1
+          if (k == (U.g.atm ? 0 : NL - 1)) q = q + ddw[it]; // topography: ocean layer nlo, atmosphere layer 1
           B.qo[fs * k + ow] = q;
         }
       }
