@@ -179,57 +179,85 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
     if (topo) q = q + B.ddynoc[o];
     B.qo[fs * kl + o] = q;
   };
-  // (the plain rows take the loop without any of the special cases: the kernel is bound by instruction issue)
-  const bool special = doS || doN || U.msg_lo || U.msg_hi;
+  // Every workgroup stores its two rows in the same plain loop (the kernel is bound by instruction issue).  The few with
+  // more to do - halo messages, a zonal boundary row - come back for it in a second pass below.
   constexpr int NST = (NC / 2 + NT - 1) / NT;
   // pos_out(2 (t + NT)) - pos_out(2 t) is a constant when 2 NT is a multiple of R1 R2
   constexpr bool STEP = (2 * NT) % PLAN::R1R2 == 0;
   const int p0 = PLAN::pos_out(2 * tid), p1 = PLAN::pos_out(2 * tid + 1);
   double a00 = 0.0, b00 = 0.0; // column 1 of the two rows (thread 0)
-  if (!special) {
 #pragma unroll
-    for (int it = 0; it < NST; ++it) {
-      const int t = tid + it * NT;
-      if (t < NC / 2) {
-        const cplx z0 = A[STEP ? p0 + it * (2 * NT / PLAN::R1R2) : PLAN::pos_out(2 * t)];
-        const cplx z1 = A[STEP ? p1 + it * (2 * NT / PLAN::R1R2) : PLAN::pos_out(2 * t + 1)];
-        const double a0 = z0.x + ha, a1 = z1.x + ha, b0 = hb - z0.y, b1 = hb - z1.y;
-        qg_store16_wt(pa + 2 * t, a0, a1);
-        if (has_b) qg_store16_wt(pb + 2 * t, b0, b1);
-        if (it == 0) {
-          a00 = a0;
-          b00 = b0;
-        }
-      }
-    }
-  } else {
-#pragma unroll 1
-    for (int t = tid; t < NC / 2; t += NT) {
-      const cplx z0 = A[PLAN::pos_out(2 * t)], z1 = A[PLAN::pos_out(2 * t + 1)];
+  for (int it = 0; it < NST; ++it) {
+    const int t = tid + it * NT;
+    if (t < NC / 2) {
+      const cplx z0 = A[STEP ? p0 + it * (2 * NT / PLAN::R1R2) : PLAN::pos_out(2 * t)];
+      const cplx z1 = A[STEP ? p1 + it * (2 * NT / PLAN::R1R2) : PLAN::pos_out(2 * t + 1)];
       const double a0 = z0.x + ha, a1 = z1.x + ha, b0 = hb - z0.y, b1 = hb - z1.y;
       qg_store16_wt(pa + 2 * t, a0, a1);
       if (has_b) qg_store16_wt(pb + 2 * t, b0, b1);
-      if (t == tid) {
+      if (it == 0) {
         a00 = a0;
         b00 = b0;
       }
-      if (U.msg_lo || U.msg_hi) {
-        msg_p(ja, 2 * t, a0); msg_p(ja, 2 * t + 1, a1);
-        msg_q(ja, 2 * t); msg_q(ja, 2 * t + 1);
-        if (has_b) {
-          msg_p(ja + 1, 2 * t, b0); msg_p(ja + 1, 2 * t + 1, b1);
-          msg_q(ja + 1, 2 * t); msg_q(ja + 1, 2 * t + 1);
+    }
+  }
+  if (doS || doN || U.msg_lo || U.msg_hi) {
+    // second pass of the workgroups at a slab edge / a zonal boundary (the transform's output is still in LDS): all they
+    // read from global memory - the topography under the boundary rows, the q rows of the halo messages - is requested
+    // for every round FIRST.  (As a loop with the loads inside, these workgroups - the last row pair's are dispatched
+    // last - paid one memory round trip per round at the very end of the launch.)
+    const bool mq_a = (U.msg_lo && ja == jlo) || (U.msg_hi && ja == jhi);
+    const bool mq_b = has_b && ((U.msg_lo && ja + 1 == jlo) || (U.msg_hi && ja + 1 == jhi));
+    auto msg_qv = [&](int gj, int col, double q) {
+      if (U.msg_lo && gj == jlo) U.msg_lo[((long)NL * 3 + kl) * ldx + col] = q;
+      if (U.msg_hi && gj == jhi) U.msg_hi[((long)NL * 3 + kl) * ldx + col] = q;
+    };
+    constexpr int CHK = 3; // rounds per batch of requests (all NST at once would not fit the registers)
+#pragma unroll
+    for (int c0 = 0; c0 < NST; c0 += CHK) {
+      double2 ddS[CHK], ddN[CHK], qa[CHK], qb[CHK];
+#pragma unroll
+      for (int i = 0; i < CHK; ++i) {
+        const int t = tid + (c0 + i) * NT, tc = (c0 + i < NST && t < NC / 2) ? t : 0;
+        // (unconditional loads from rows that exist, the values selected afterwards: `cond ? *p : zero` made the
+        //  compiler select between the ADDRESS p and a zero kept in scratch memory, and load through a flat pointer)
+        const double2 vS = *reinterpret_cast<const double2 *>(B.ddynoc + (doS ? (long)(jS - 1) * ldx : 0) + 2 * tc);
+        const double2 vN = *reinterpret_cast<const double2 *>(B.ddynoc + (doN ? (long)(jN - 1) * ldx : 0) + 2 * tc);
+        qa[i] = *reinterpret_cast<const double2 *>(B.qo + fs * kl + (long)(ja - 1) * ldx + 2 * tc);
+        qb[i] = *reinterpret_cast<const double2 *>(B.qo + fs * kl + (long)(has_b ? ja : ja - 1) * ldx + 2 * tc);
+        ddS[i].x = (doS && topo) ? vS.x : 0.0;
+        ddS[i].y = (doS && topo) ? vS.y : 0.0;
+        ddN[i].x = (doN && topo) ? vN.x : 0.0;
+        ddN[i].y = (doN && topo) ? vN.y : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < CHK; ++i) {
+        const int t = tid + (c0 + i) * NT;
+        if (c0 + i < NST && t < NC / 2) {
+          const cplx z0 = A[PLAN::pos_out(2 * t)], z1 = A[PLAN::pos_out(2 * t + 1)];
+          const double a0 = z0.x + ha, a1 = z1.x + ha, b0 = hb - z0.y, b1 = hb - z1.y;
+          if (U.msg_lo || U.msg_hi) {
+            msg_p(ja, 2 * t, a0); msg_p(ja, 2 * t + 1, a1);
+            if (mq_a) { msg_qv(ja, 2 * t, qa[i].x); msg_qv(ja, 2 * t + 1, qa[i].y); }
+            if (has_b) {
+              msg_p(ja + 1, 2 * t, b0); msg_p(ja + 1, 2 * t + 1, b1);
+              if (mq_b) { msg_qv(ja + 1, 2 * t, qb[i].x); msg_qv(ja + 1, 2 * t + 1, qb[i].y); }
+            }
+          }
+          if (doS) {
+            const long o = (long)(jS - 1) * ldx + 2 * t;
+            *reinterpret_cast<double2 *>(U.pnew + fs * kl + o) = double2{hSk, hSk};
+            const double q0 = fft3u_bdy_q<NL>(B, kl, hS, a0, byS) + ddS[i].x, q1 = fft3u_bdy_q<NL>(B, kl, hS, a1, byS) + ddS[i].y;
+            *reinterpret_cast<double2 *>(B.qo + fs * kl + o) = double2{q0, q1};
+          }
+          if (doN) {
+            const long o = (long)(jN - 1) * ldx + 2 * t;
+            *reinterpret_cast<double2 *>(U.pnew + fs * kl + o) = double2{hNk, hNk};
+            const double n0 = has_b ? b0 : a0, n1 = has_b ? b1 : a1;
+            const double q0 = fft3u_bdy_q<NL>(B, kl, hN, n0, byN) + ddN[i].x, q1 = fft3u_bdy_q<NL>(B, kl, hN, n1, byN) + ddN[i].y;
+            *reinterpret_cast<double2 *>(B.qo + fs * kl + o) = double2{q0, q1};
+          }
         }
-      }
-      if (doS) {
-        qg_store16_wt(U.pnew + fs * kl + (long)(jS - 1) * ldx + 2 * t, hSk, hSk);
-        bdy_col(true, 2 * t, a0);
-        bdy_col(true, 2 * t + 1, a1);
-      }
-      if (doN) {
-        qg_store16_wt(U.pnew + fs * kl + (long)(jN - 1) * ldx + 2 * t, hNk, hNk);
-        bdy_col(false, 2 * t, has_b ? b0 : a0);
-        bdy_col(false, 2 * t + 1, has_b ? b1 : a1);
       }
     }
   }

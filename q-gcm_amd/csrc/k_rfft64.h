@@ -200,12 +200,15 @@ __global__ __launch_bounds__(D64_NT) void k_rfft64(const QgDstParams P) {
 // CONSTR: the constraint wave runs constr_cyc_partB (c1, c2, c3 from the zonal-mean column the Thomas sweep left in
 // wrk; part A - boundary sums, leapfrog of the constraint vectors - ran in the Thomas launch) redundantly in every
 // workgroup, hidden behind the transforms; workgroup 0 records the scalars (dpiat / dpioc, c1, c2, c3, xinhom).
+// Its parameters come BY VALUE (kernel arguments: scalar loads, pointers known to be global): read through a pointer to a
+// device copy, every field was a flat load and every array behind it a second, dependent round trip - in the wave
+// the other three wait for.
 // grid: (npairs), block 64*(NL + CONSTR)
 // ---------------------------------------------------------------------------
 template <int M, int NL, bool BDY, bool CONSTR>
 __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_rfft64_unpack(const QgDstParams P, const QgUnpackParams U,
                                                                                  const QgBdyParams B,
-                                                                                 const QgCycConstrParams *Qp) {
+                                                                                 const QgCycConstrParams Q) {
   constexpr int N = 64 * M;
   __shared__ __align__(16) cplx Fsh[NL][M * D64_ROW];
   __shared__ __align__(16) cplx W64sh[NL][64];
@@ -218,10 +221,10 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_rfft64_unpack(
     double c1[NL], c2[NL], c3, ocs[NL], ocn[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) { // the new constraint vectors: part A ran in the Thomas launch
-      ocs[k] = Qp->sc->ocncs[k];
-      ocn[k] = Qp->sc->ocncn[k];
+      ocs[k] = Q.sc->ocncs[k];
+      ocn[k] = Q.sc->ocncn[k];
     }
-    constr_cyc_partB<NL>(*Qp, lane, blockIdx.x == 0, ocs, ocn, c1, c2, c3);
+    constr_cyc_partB<NL>(Q, lane, blockIdx.x == 0, ocs, ocn, c1, c2, c3);
     if (lane == 0) {
 #pragma unroll
       for (int m = 0; m < NL - 1; ++m) {

@@ -1294,13 +1294,15 @@ static int launch_rfft_unpack(qgcm_hip_ctx *c, bool fuse_bdy, bool constr) {
   QgBdyParams B;
   fill_bdy_params(c, B);
   if (constr && !c->d_cycq) QG_FAIL("k_rfft64_unpack: homogeneous solutions not set");
+  QgCycConstrParams Qv; // by value: kernel arguments (k_rfft64.h)
+  fill_cyc_constr_params(c, Qv);
   const int nrows = g.jr1 - g.jr0 + 1;
   dim3 grid((nrows + 1) / 2);
   KTimer t(c, KN_DSTI);
 #define QG_RU(MV, NLV)                                                                                                        \
-  if (fuse_bdy && constr) hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); \
-  else if (fuse_bdy) hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq); \
-  else hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, (const QgCycConstrParams *)c->d_cycq)
+  if (fuse_bdy && constr) hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, Qv); \
+  else if (fuse_bdy) hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, Qv); \
+  else hipLaunchKernelGGL((k_rfft64_unpack<MV, NLV, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, Qv)
 #define QG_RU_NL(MV)                 \
   switch (g.nl) {                    \
     case 2: QG_RU(MV, 2); break;     \
