@@ -504,6 +504,9 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
     if (HALO && U.msg_lo && gj == jlo) U.msg_lo[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
     if (HALO && U.msg_hi && gj == jhi) U.msg_hi[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
   };
+  // fused leapfrog averaging (QgUnpackParams.pavg / qavg; wave-uniform branches, one step in 25): the value stored for
+  // the new po at field offset idx
+  auto avg_p = [&](long idx, double v) { return U.pavg ? 0.5 * (v + U.pavg[idx]) : v; };
   // unpack_point of k_misc.h with the transformed rows taken from LDS; sel: 0 row a, 1 row b, -1 wall row;
   // ocv: prefetched ochom values of the point, or nullptr (read them here)
   auto point = [&](int gi, int gj, int sel, const double *ocv, double *pl) {
@@ -534,6 +537,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
       double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
       if (k == NL - 1) q = q + dd;
+      if (U.qavg) q = 0.5 * (q + U.qavg[fs * k + o]);
       B.qo[fs * k + o] = q;
       msg_q(gi, gj, k, q);
     }
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       double pl[NL];
       point(gw, gj, r, w.ocw[r], pl);
 #pragma unroll
-      for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = pl[k];
+      for (int k = 0; k < NL; ++k) U.pnew[fs * k + o] = avg_p(fs * k + o, pl[k]);
       msg_p(gw, gj, pl);
       if (BDY || side == 0) {
         double pin[NL];
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
           // column 2: the interior columns are combined in 16-byte pairs (3,4) .. (nx-2, nx-1) - this one is left over
           const long on = (long)(gj - 1) * U.g.ldx + (gn - 1);
 #pragma unroll
-          for (int k = 0; k < NL; ++k) U.pnew[fs * k + on] = pin[k];
+          for (int k = 0; k < NL; ++k) U.pnew[fs * k + on] = avg_p(fs * k + on, pin[k]);
           msg_p(gn, gj, pin);
           if (HALO && ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi))) {
 #pragma unroll
@@ -680,8 +684,16 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       }
       point(gi, gj, r, oca, pla);
       point(gi + 1, gj, r, ocb, plb);
+      if (U.pavg) {
 #pragma unroll
-      for (int k = 0; k < NL; ++k) qg_store16_wt(U.pnew + fs * k + o, pla[k], plb[k]);
+        for (int k = 0; k < NL; ++k) {
+          const double2 pc = *reinterpret_cast<const double2 *>(U.pavg + fs * k + o);
+          qg_store16_wt(U.pnew + fs * k + o, 0.5 * (pla[k] + pc.x), 0.5 * (plb[k] + pc.y));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) qg_store16_wt(U.pnew + fs * k + o, pla[k], plb[k]);
+      }
       msg_p(gi, gj, pla);
       msg_p(gi + 1, gj, plb);
       if (HALO && ((U.msg_lo && gj == jlo) || (U.msg_hi && gj == jhi))) { // interior columns of the q row: set by k_tend
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
         double pw[NL], pl[NL];
         point(gi, wall, -1, ocw[it], pw);
 #pragma unroll
-        for (int k = 0; k < NL; ++k) U.pnew[fs * k + ow] = pw[k];
+        for (int k = 0; k < NL; ++k) U.pnew[fs * k + ow] = avg_p(fs * k + ow, pw[k]);
         if (BDY) {
           point(gi, gj, r, oci[it], pl);
           bdy_q(ow, pw, pl, byw, ddw[it], gi, wall);

@@ -354,6 +354,12 @@ __global__ __launch_bounds__(256) void k_lf_average(double *qo, const double *qo
   }
 }
 
+// the scalar part alone: the fields were averaged by the step's own kernels (QgTendParams.avg, QgUnpackParams.pavg)
+__global__ void k_lf_average_scalars(QgScalars *sc, int nl) {
+  if (threadIdx.x == 0)
+    for (int k = 0; k < nl - 1; ++k) sc->dpioc[k] = 0.5 * (sc->dpioc[k] + sc->dpiocp[k]);
+}
+
 // ---------------------------------------------------------------------------
 // y-slab halo messages: 3 rows of po and 1 row of qo per layer and direction.
 // message = [k][3 rows][ldx] of p, then [k][ldx] of q.   grid: (ceil(ldx/256), 4*nl, 2)

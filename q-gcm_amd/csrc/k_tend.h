@@ -87,7 +87,7 @@ __host__ __device__ __forceinline__ TendTiling tend_tiling(const QgGeom &g) {
 
 // Point-wise part of the step for one p-point and all layers (qgosubs.F:173-219, ocisubs.F:117-139):
 // dq = dqdt of the point (0 outside the interior), d2bot = Del^2(pom) of the bottom layer,
-// qm / qo = old qom / qo of the point.
+// qm / qo = old qom / qo of the point (qo: only read on rows that are not stepped, and with P.avg).
 // PAIR (the tile kernel's epilogue: EVERY lane of the wave calls, `valid` says whether its point exists): the new qo
 // and the work array leave as 16-byte write-through stores of two neighbouring columns (qgcm_dev.h: the 44 MB this
 // kernel writes no longer wait, dirty in L2, for the end-of-kernel flush); !PAIR: plain stores (edge workgroups).
@@ -125,11 +125,13 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
     // sponge layer of the k247 fork (src/qgosubs.F:203-205), association as written there; a wave-uniform branch on a
     // kernel argument, not taken in any BASELINE configuration
     if (P.rspl) qn = qn + P.tdc1 * P.rspl[valid ? o : 0] * (qm[k] - betay);
+    // (P.avg: the leapfrog averaging that follows this step, src/q-gcm.F:1345-1351 - wave-uniform, one step in 25)
+    const double qs = P.avg ? 0.5 * (qn + qo[k]) : qn;
     if (PAIR) {
       // (rows not stepped keep qo, qgosubs.F:214-219; o is even on even lanes: the tile starts at an odd column)
-      qg_pair_store_wt(P.qnew + fs * k + o, wallrow ? qo[k] : qn, valid);
+      qg_pair_store_wt(P.qnew + fs * k + o, wallrow ? qo[k] : qs, valid);
     } else {
-      P.qnew[fs * k + o] = qn;
+      P.qnew[fs * k + o] = qs;
     }
     ql[k] = qn - betay;
   }
@@ -176,7 +178,7 @@ __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTilin
   for (int k = 0; k < NL; ++k) {
     dq[k] = 0.0;
     qm[k] = wallrow ? 0.0 : P.qnew[fs * k + o];
-    qo[k] = wallrow ? P.qo[fs * k + o] : 0.0;
+    qo[k] = (wallrow || P.avg) ? P.qo[fs * k + o] : 0.0; // (P.avg: tend_point stores 0.5*(new qo + qo))
   }
   double d2bot = 0.0, wek = 0.0, ent = 0.0, ddy = 0.0;
   if (!wallrow) { // then gi == nx: E wall column of a stepped row
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       for (int k = 0; k < NL; ++k) {
         dqp[k] = dq[k][r];
         qmp[k] = e_qm[k][r];
-        qop[k] = wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+        qop[k] = (wallrow || P.avg) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
       }
       tend_point<NL, CYC, true>(P, gi0, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r], valid);
     }
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       for (int k = 0; k < NL; ++k) {
         dqp[k] = dq[k][r];
         qmp[k] = e_qm[k][r];
-        qop[k] = wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+        qop[k] = (wallrow || P.avg) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
       }
       tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
     }

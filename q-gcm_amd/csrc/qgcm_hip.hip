@@ -124,6 +124,8 @@ struct qgcm_hip_ctx {
   bool force_generic_dst; // QGCM_HIP_GENERIC_DST=1: use the generic Stockham row kernel (A/B + tests)
   bool no_fused_unpack;   // QGCM_HIP_NO_FUSED_UNPACK=1: separate inverse transform and unpack launches (A/B + tests)
   int cu_first = 0, cu_count = 0; // qgcm_hip_set_cu_range: the CUs this handle's stream may use (0: all)
+  bool no_fused_avg;      // QGCM_HIP_NO_FUSED_AVG=1: leapfrog averaging as a launch of its own inside qgcm_hip_steps (A/B + tests)
+  bool avg_now = false;   // one_step: this step's kernels store the averaged time level (k_tend, k_dst64_unpack)
   bool no_fused_constr;   // QGCM_HIP_NO_FUSED_CONSTR=1: keep the k_constr_box launch inside qgcm_hip_steps (A/B + tests)
   bool tend_wide;         // QGCM_HIP_TEND_WIDE=1: the tendency kernel's HBM-bound instantiation (32-wide tiles, plain stores) at any size (tests)
   std::vector<double> bd2oc;
@@ -307,6 +309,8 @@ extern "C" int qgcm_hip_create(qgcm_hip_handle *h, const qgcm_hip_params *prm, i
     c->no_fused_constr = fc && fc[0] == '1';
     const char *tw = getenv("QGCM_HIP_TEND_WIDE");
     c->tend_wide = tw && tw[0] == '1';
+    const char *fa = getenv("QGCM_HIP_NO_FUSED_AVG");
+    c->no_fused_avg = fa && fa[0] == '1';
   }
   c->profiling = false;
   HIPCHECK(hipEventCreate(&c->ev0));
@@ -919,6 +923,7 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   P.upd_dpi = upd_dpi ? 1 : 0;
   P.rspl = c->rspl;
   P.tdc1 = pr.tdto * c->c1_spl; // tdto*c1_spl, src/qgosubs.F:204
+  P.avg = c->avg_now ? 1 : 0;
   for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
   // write-through pair stores of the new qo and 16-wide tiles while the step's working set (~ 7 nl - 1 fields) stays in the
   // 256 MiB Infinity Cache (NAtl 5 km: 150 MB: -1 us per step; SOcn 5 km's 425 MB: +8 us); plain stores and 32-wide
@@ -1397,6 +1402,11 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nu
   P.sc = c->sc;
   P.msg_lo = msg_lo;
   P.msg_hi = msg_hi;
+  if (c->avg_now) {
+    if (msg_lo || msg_hi || !fuse_bdy) QG_FAIL("k_dst64_unpack: the fused leapfrog averaging belongs to whole-domain steps");
+    P.pavg = c->p[c->ip];     // this step's po (the launch writes the old pom buffer)
+    P.qavg = c->q[c->iq ^ 1]; // this step's qo (iq already points at the new qo)
+  }
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
   QgBdyParams B;
   fill_bdy_params(c, B);
@@ -1968,10 +1978,25 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   if (c->oml.on && launch_oml(c, false)) return 1; // src/q-gcm.F:1232; its final reduction rides in launch_tend
   const bool fused_constr = !c->g.cyc && can_fuse_dst_unpack(c) && !c->no_fused_constr; // see ocinvq_impl
   if (check_ready(c, "qgcm_hip_steps")) return 1;
-  if (launch_tend(c, fused_constr, c->oml.on)) return 1;
-  c->iq ^= 1; // as qgcm_hip_qgostep
-  if (ocinvq_impl(c, true, true)) return 1; // ocqbdy fused into the unpack kernel
-  if ((s - 1) % c->avg_period == 0) {
+  // Leapfrog averaging (src/q-gcm.F:1345-1351) after this step: where the box ocean's fused kernels run, they store the
+  // averaged level themselves - k_tend the interior qo (both levels are in its registers), k_dst64_unpack the new po and
+  // the boundary qo (one extra read of this step's po) - instead of a pass of its own over six fields (133 MB at 5 km,
+  // 21 us every 25 steps); the integrals dpioc follow in a one-thread launch.  Same expressions: bitwise the same fields.
+  const bool avg = (s - 1) % c->avg_period == 0;
+  c->avg_now = avg && fused_constr && !c->oml.on && !c->no_fused_avg;
+  const bool avg_fused = c->avg_now;
+  int rc = launch_tend(c, fused_constr, c->oml.on);
+  if (!rc) {
+    c->iq ^= 1; // as qgcm_hip_qgostep
+    rc = ocinvq_impl(c, true, true); // ocqbdy fused into the unpack kernel
+  }
+  c->avg_now = false;
+  if (rc) return 1;
+  if (avg_fused) {
+    KTimer t(c, KN_LFAVG);
+    hipLaunchKernelGGL(k_lf_average_scalars, dim3(1), dim3(64), 0, c->stream, c->sc, c->g.nl);
+    HIPCHECK(hipGetLastError());
+  } else if (avg) {
     if (qgcm_hip_lf_average(c)) return 1; // incl. sst when the mixed layer is on
   }
   if (c->profiling) {

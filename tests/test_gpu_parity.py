@@ -1391,3 +1391,48 @@ def test_homsol_on_y_slabs(nranks):
         for sl in slabs:
             sl.close()
         o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlo", [2, 3, 4])
+def test_fused_leapfrog_average_is_bitwise(nlo, monkeypatch):
+    """Inside qgcm_hip_steps the box ocean's fused kernels store the averaged time level themselves on the steps that the
+    reference follows with its leapfrog averaging (src/q-gcm.F:1345-1351): k_tend the interior qo, k_dst64_unpack the
+    new po and the boundary qo, a one-thread launch the integrals dpioc.  QGCM_HIP_NO_FUSED_AVG=1 keeps the pass of its
+    own (k_lf_average, the form the reference fixtures of test_whole_steps_vs_reference pin at the generic sizes): the
+    two are bit for bit the same after 1, 26 and 60 steps (averaging after steps 1, 26, 51), graph replay and eager."""
+    from qgcm_hip import OceanModel, synth
+    from qgcm_hip.config import OceanConfig
+    lay = {2: dict(hoc=(500.0, 3500.0), gpoc=(0.02,), ah2oc=(0.0, 0.0), ah4oc=(1.2e10,) * 2),
+           3: dict(hoc=(350.0, 750.0, 2900.0), gpoc=(0.025, 0.0125), ah2oc=(0.0,) * 3, ah4oc=(1.2e10,) * 3),
+           4: dict(hoc=(300.0, 500.0, 1200.0, 2000.0), gpoc=(0.02, 0.01, 0.005), ah2oc=(0.0,) * 4, ah4oc=(1.2e10,) * 4)}[nlo]
+    cfg = OceanConfig("nl%d_box_avg" % nlo, 16, 10, 12, 6, 16, nlo, dxo=2.5e4, dta=240.0, fnot=9.37456e-05, beta=1.7536e-11,
+                      cyclic=False, **lay)
+    assert cfg.nxto == 192  # the wave-per-row-pair kernels
+    po = synth.gaussian_eddy(cfg, noise=2e-2, seed=5)
+    pom = np.asfortranarray(0.99 * po)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    xon = np.zeros(nlo - 1)
+    xon[0] = 3e2
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("QGCM_HIP_NO_FUSED_AVG", flag)
+        m = OceanModel(cfg)
+        try:
+            m.set_p(po, pom)
+            m.set_forcing(wek, np.zeros_like(wek), xon)
+            snaps = []
+            m.steps(1, s0=1)   # one eager step, followed by the averaging
+            snaps.append((m.get_state(), m.get_scalars()))
+            m.steps(25, s0=2)  # ... step 26 averages again
+            snaps.append((m.get_state(), m.get_scalars()))
+            m.steps(34, s0=27)  # a captured block across the averaging after step 51
+            snaps.append((m.get_state(), m.get_scalars()))
+            out[flag] = snaps
+        finally:
+            m.close()
+    for (sa, ca), (sb, cb) in zip(out["1"], out["0"]):
+        for f, x, y in zip(FIELDS, sa, sb):
+            assert np.array_equal(x, y), f
+        assert np.array_equal(np.asarray(ca), np.asarray(cb))
