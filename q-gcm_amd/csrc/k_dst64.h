@@ -470,7 +470,9 @@ __global__ __launch_bounds__(D64_NT) void k_dst64(const QgDstParams P) {
 // barrier that follows the transform.  dpioc has been stepped by k_tend.  Workgroup 0 records xinhom / hclco.
 // Same functions as k_constr_box, contraction off: bitwise the same coefficients.
 // ---------------------------------------------------------------------------
-template <int M, int NL, bool BDY, bool HALO, bool CONSTR>
+// AVG: the leapfrog averaging that follows the step (src/q-gcm.F:1345-1351) folded into the stores (QgUnpackParams.pavg /
+// qavg) - a template flag, instantiated for the whole-domain step only: the other 24 steps of 25 run the plain code.
+template <int M, int NL, bool BDY, bool HALO, bool CONSTR, bool AVG = false>
 __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(const QgDstParams P, const QgUnpackParams U,
                                                                                       const QgBdyParams B, const QgConstrLite C) {
   constexpr int N = 64 * M, NP = N + N / 16;
@@ -504,9 +506,8 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
     if (HALO && U.msg_lo && gj == jlo) U.msg_lo[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
     if (HALO && U.msg_hi && gj == jhi) U.msg_hi[((long)NL * 3 + k) * ldxm + (gi - 1)] = q;
   };
-  // fused leapfrog averaging (QgUnpackParams.pavg / qavg; wave-uniform branches, one step in 25): the value stored for
-  // the new po at field offset idx
-  auto avg_p = [&](long idx, double v) { return U.pavg ? 0.5 * (v + U.pavg[idx]) : v; };
+  // fused leapfrog averaging: the value stored for the new po at field offset idx
+  auto avg_p = [&](long idx, double v) { return AVG ? 0.5 * (v + U.pavg[idx]) : v; };
   // unpack_point of k_misc.h with the transformed rows taken from LDS; sel: 0 row a, 1 row b, -1 wall row;
   // ocv: prefetched ochom values of the point, or nullptr (read them here)
   auto point = [&](int gi, int gj, int sel, const double *ocv, double *pl) {
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       else ap = B.f0A[k + NL * (k - 1)] * pl[k - 1] + B.f0A[k + NL * k] * pl[k] + B.f0A[k + NL * (k + 1)] * pl[k + 1];
       double q = B.bcfaco_f0 * (pin[k] - pl[k]) - ap + by;
       if (k == NL - 1) q = q + dd;
-      if (U.qavg) q = 0.5 * (q + U.qavg[fs * k + o]);
+      if (AVG) q = 0.5 * (q + U.qavg[fs * k + o]);
       B.qo[fs * k + o] = q;
       msg_q(gi, gj, k, q);
     }
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       }
       point(gi, gj, r, oca, pla);
       point(gi + 1, gj, r, ocb, plb);
-      if (U.pavg) {
+      if (AVG) {
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
           const double2 pc = *reinterpret_cast<const double2 *>(U.pavg + fs * k + o);

@@ -87,11 +87,14 @@ __host__ __device__ __forceinline__ TendTiling tend_tiling(const QgGeom &g) {
 
 // Point-wise part of the step for one p-point and all layers (qgosubs.F:173-219, ocisubs.F:117-139):
 // dq = dqdt of the point (0 outside the interior), d2bot = Del^2(pom) of the bottom layer,
-// qm / qo = old qom / qo of the point (qo: only read on rows that are not stepped, and with P.avg).
+// qm / qo = old qom / qo of the point (qo: only read on rows that are not stepped, and with AVG).
 // PAIR (the tile kernel's epilogue: EVERY lane of the wave calls, `valid` says whether its point exists): the new qo
 // and the work array leave as 16-byte write-through stores of two neighbouring columns (qgcm_dev.h: the 44 MB this
 // kernel writes no longer wait, dirty in L2, for the end-of-kernel flush); !PAIR: plain stores (edge workgroups).
-template <int NL, bool CYC, bool PAIR = false>
+// AVG: the leapfrog averaging that follows this step (src/q-gcm.F:1345-1351) is folded into the store of the new qo:
+// 0.5*(new qo + qo); the projection keeps the un-averaged value.  A template flag: as a kernel argument the extra
+// branches cost the other 24 steps of 25 more than the averaging pass had (measured: +0.5 us per step at 5 km).
+template <int NL, bool CYC, bool PAIR = false, bool AVG = false>
 __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj, const double *dq, double d2bot,
                                            const double *qm, const double *qo, double wek, double ent, double ddy,
                                            bool valid = true) {
@@ -125,8 +128,7 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
     // sponge layer of the k247 fork (src/qgosubs.F:203-205), association as written there; a wave-uniform branch on a
     // kernel argument, not taken in any BASELINE configuration
     if (P.rspl) qn = qn + P.tdc1 * P.rspl[valid ? o : 0] * (qm[k] - betay);
-    // (P.avg: the leapfrog averaging that follows this step, src/q-gcm.F:1345-1351 - wave-uniform, one step in 25)
-    const double qs = P.avg ? 0.5 * (qn + qo[k]) : qn;
+    const double qs = AVG ? 0.5 * (qn + qo[k]) : qn;
     if (PAIR) {
       // (rows not stepped keep qo, qgosubs.F:214-219; o is even on even lanes: the tile starts at an odd column)
       qg_pair_store_wt(P.qnew + fs * k + o, wallrow ? qo[k] : qs, valid);
@@ -155,7 +157,7 @@ __device__ __forceinline__ void tend_point(const QgTendParams &P, int gi, int gj
 
 // Edge work of the box ocean: the E wall column (dqdt = 0, qgosubs.F:371,397; Del^2 of the bottom layer by
 // the wall rule :112,125) and the N wall row (not stepped), one point per thread.
-template <int NL>
+template <int NL, bool AVG = false>
 __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTiling &T, int eblock) {
   const QgGeom &g = P.g;
   const int rows = g.jhi - g.jlo + 1;
@@ -178,7 +180,7 @@ __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTilin
   for (int k = 0; k < NL; ++k) {
     dq[k] = 0.0;
     qm[k] = wallrow ? 0.0 : P.qnew[fs * k + o];
-    qo[k] = (wallrow || P.avg) ? P.qo[fs * k + o] : 0.0; // (P.avg: tend_point stores 0.5*(new qo + qo))
+    qo[k] = (wallrow || AVG) ? P.qo[fs * k + o] : 0.0; // (AVG: tend_point stores 0.5*(new qo + qo))
   }
   double d2bot = 0.0, wek = 0.0, ent = 0.0, ddy = 0.0;
   if (!wallrow) { // then gi == nx: E wall column of a stepped row
@@ -188,18 +190,21 @@ __device__ __forceinline__ void tend_edge(const QgTendParams &P, const TendTilin
     ent = P.entoc[o];
     ddy = P.ddynoc[o];
   }
-  tend_point<NL, false>(P, gi, gj, dq, d2bot, qm, qo, wek, ent, ddy);
+  tend_point<NL, false, false, AVG>(P, gi, gj, dq, d2bot, qm, qo, wek, ent, ddy);
 }
 
 // WTQ: the epilogue stores the new qo in write-through pairs (tend_point<.., PAIR>) - worth 1 us per step while the
 // step's working set stays in the Infinity Cache (NAtl 5 km), but it costs 6 VGPRs (78: six waves per SIMD instead of
 // seven) and at HBM-bound sizes, where L2's own full-line evictions already spread the writes over the kernel, it made
 // the kernel slower (SOcn 5 km 95 -> 103 us, written through or not): the host picks the instantiation by size.
-template <int NL, bool CYC, bool WTQ>
+template <int NL, bool CYC, bool WTQ, bool AVG = false>
 #ifndef TEND_WAVES_PER_EU
 #define TEND_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTendParams P, const QgCycSumParams S,
+#ifndef TEND_WAVES_WTQ
+#define TEND_WAVES_WTQ 4
+#endif
+__global__ __launch_bounds__(TEND_NT, (WTQ && NL <= 4) ? TEND_WAVES_WTQ : TEND_WAVES_PER_EU) void k_tend(const QgTendParams P, const QgCycSumParams S,
                                                                      const QgOmlFinal F) {
 #ifndef TEND_EXPERIMENT // (tile-shape A/B builds without the mixed layer: profiles/r4_tend_shapes_socn5.log)
   static_assert(TEND_NT == OML_NT, "oml_final_block runs in workgroup 0 of this kernel");
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
   if ((int)blockIdx.x >= 8 * per_xcd) {
     // cyclic / atmosphere: the boundary line sums for the momentum constraints (k_cyclic.h); box: the wall edges
     if (CYC) cyc_bsums_block(S, (int)blockIdx.x - 8 * per_xcd);
-    else tend_edge<NL>(P, T, (int)blockIdx.x - 8 * per_xcd);
+    else tend_edge<NL, AVG>(P, T, (int)blockIdx.x - 8 * per_xcd);
     return;
   }
   const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -438,9 +443,9 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       for (int k = 0; k < NL; ++k) {
         dqp[k] = dq[k][r];
         qmp[k] = e_qm[k][r];
-        qop[k] = (wallrow || P.avg) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+        qop[k] = (wallrow || AVG) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
       }
-      tend_point<NL, CYC, true>(P, gi0, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r], valid);
+      tend_point<NL, CYC, true, AVG>(P, gi0, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r], valid);
     }
   } else {
 #pragma unroll
@@ -454,9 +459,9 @@ __global__ __launch_bounds__(TEND_NT, TEND_WAVES_PER_EU) void k_tend(const QgTen
       for (int k = 0; k < NL; ++k) {
         dqp[k] = dq[k][r];
         qmp[k] = e_qm[k][r];
-        qop[k] = (wallrow || P.avg) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+        qop[k] = (wallrow || AVG) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
       }
-      tend_point<NL, CYC>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
+      tend_point<NL, CYC, false, AVG>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
     }
   }
   QG_STAMP(3, 7);

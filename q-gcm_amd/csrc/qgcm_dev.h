@@ -131,9 +131,6 @@ struct QgTendParams {
   // nullptr (every BASELINE configuration): the term is absent
   const double *rspl;
   double tdc1;
-  // leapfrog averaging fused into the step that precedes it (src/q-gcm.F:1345-1351, qo = 0.5*(qo + qom) right after
-  // this step): the interior qo leaves as 0.5*(new qo + qo of this step); the projection keeps the un-averaged value
-  int avg;
 };
 
 struct QgDstParams {
@@ -188,9 +185,9 @@ struct QgUnpackParams {
   const double *ochom;
   double *pnew; // old pom buffer, receives the new po
   double *msg_lo, *msg_hi; // y-slab halo messages (k_misc.h layout) written by the fused unpack, or nullptr
-  // leapfrog averaging fused into k_dst64_unpack (src/q-gcm.F:1345-1351: po = 0.5*(po + pom), qo = 0.5*(qo + qom) right
+  // leapfrog averaging fused into k_dst64_unpack<.., AVG> (src/q-gcm.F:1345-1351: po = 0.5*(po + pom), qo = 0.5*(qo + qom) right
   // after this step): pavg = the po of this step (pom by then), qavg = the qo of this step; the new po and the boundary
-  // qo are stored averaged (the boundary PV is formed from the un-averaged po, as the reference's ocqbdy is).  nullptr: off
+  // qo are stored averaged (the boundary PV is formed from the un-averaged po, as the reference's ocqbdy is)
   const double *pavg, *qavg;
   const QgScalars *sc;
   const double *pch1, *pch2, *pbh; // cyclic (ny, nl-1), (ny)

@@ -895,6 +895,12 @@ static bool tend_can_split(const qgcm_hip_ctx *c) {
   return T.gy >= 3;
 }
 
+// write-through pair stores of the new qo (and 16-wide tiles) while the fields fit the Infinity Cache; plain stores and
+// 32-wide tiles beyond (k_tend.h)
+static bool tend_wtq(const qgcm_hip_ctx *c) {
+  return (double)c->g.fstride * 8.0 * (7 * c->g.nl - 1) < 200.0e6 && !c->tend_wide;
+}
+
 static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = false, int part = TEND_ALL) {
   const QgGeom &g = c->g;
   const qgcm_hip_params &pr = c->prm;
@@ -923,12 +929,12 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   P.upd_dpi = upd_dpi ? 1 : 0;
   P.rspl = c->rspl;
   P.tdc1 = pr.tdto * c->c1_spl; // tdto*c1_spl, src/qgosubs.F:204
-  P.avg = c->avg_now ? 1 : 0;
   for (int k = 0; k < g.nl; ++k) P.gpoc[k] = pr.gpoc[k];
   // write-through pair stores of the new qo and 16-wide tiles while the step's working set (~ 7 nl - 1 fields) stays in the
   // 256 MiB Infinity Cache (NAtl 5 km: 150 MB: -1 us per step; SOcn 5 km's 425 MB: +8 us); plain stores and 32-wide
   // tiles at the HBM-bound sizes (k_tend.h)
-  const bool wtq = (double)g.fstride * 8.0 * (7 * g.nl - 1) < 200.0e6 && !c->tend_wide;
+  const bool wtq = tend_wtq(c);
+  if (c->avg_now && (!wtq || g.cyc || g.nl > 4 || part != TEND_ALL)) QG_FAIL("k_tend: the fused leapfrog averaging belongs to whole-domain box steps");
   const TendTiling T = g.cyc ? (wtq ? tend_tiling<true, TEND_TX>(g) : tend_tiling<true, TEND_TX_WIDE>(g))
                              : (wtq ? tend_tiling<false, TEND_TX>(g) : tend_tiling<false, TEND_TX_WIDE>(g));
   if (part != TEND_ALL && T.gy < 3) QG_FAIL("k_tend: a slab of fewer than three tile rows cannot be split");
@@ -955,6 +961,13 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   else if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);     \
   else if (wtq) hipLaunchKernelGGL((k_tend<NLV, false, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);       \
   else hipLaunchKernelGGL((k_tend<NLV, false, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F)
+  if (c->avg_now) { // the step before a leapfrog averaging stores the averaged qo itself (one_step)
+    switch (g.nl) {
+      case 2: hipLaunchKernelGGL((k_tend<2, false, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F); break;
+      case 3: hipLaunchKernelGGL((k_tend<3, false, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F); break;
+      default: hipLaunchKernelGGL((k_tend<4, false, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F); break;
+    }
+  } else
   switch (g.nl) {
     case 2: QG_TEND(2); break;
     case 3: QG_TEND(3); break;
@@ -1403,7 +1416,7 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nu
   P.msg_lo = msg_lo;
   P.msg_hi = msg_hi;
   if (c->avg_now) {
-    if (msg_lo || msg_hi || !fuse_bdy) QG_FAIL("k_dst64_unpack: the fused leapfrog averaging belongs to whole-domain steps");
+    if (msg_lo || msg_hi || !fuse_bdy || !constr) QG_FAIL("k_dst64_unpack: the fused leapfrog averaging belongs to whole-domain steps");
     P.pavg = c->p[c->ip];     // this step's po (the launch writes the old pom buffer)
     P.qavg = c->q[c->iq ^ 1]; // this step's qo (iq already points at the new qo)
   }
@@ -1424,7 +1437,8 @@ static int launch_dst_unpack(qgcm_hip_ctx *c, bool fuse_bdy, double *msg_lo = nu
   dim3 grid((nrows + 1) / 2);
   KTimer t(c, KN_DSTI);
 #define QG_DU(MV, NLV)                                                                                                  \
-  if ((msg_lo || msg_hi) && constr) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
+  if (c->avg_now) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
+  else if ((msg_lo || msg_hi) && constr) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
   else if (msg_lo || msg_hi) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, true, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C); \
   else if (fuse_bdy && constr) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, true>), grid, dim3(64 * (NLV + 1)), 0, c->stream, D, P, B, C); \
   else if (fuse_bdy) hipLaunchKernelGGL((k_dst64_unpack<MV, NLV, true, false, false>), grid, dim3(64 * NLV), 0, c->stream, D, P, B, C);  \
@@ -1983,7 +1997,7 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   // the boundary qo (one extra read of this step's po) - instead of a pass of its own over six fields (133 MB at 5 km,
   // 21 us every 25 steps); the integrals dpioc follow in a one-thread launch.  Same expressions: bitwise the same fields.
   const bool avg = (s - 1) % c->avg_period == 0;
-  c->avg_now = avg && fused_constr && !c->oml.on && !c->no_fused_avg;
+  c->avg_now = avg && fused_constr && c->g.nl <= 4 && tend_wtq(c) && !c->oml.on && !c->no_fused_avg;
   const bool avg_fused = c->avg_now;
   int rc = launch_tend(c, fused_constr, c->oml.on);
   if (!rc) {
