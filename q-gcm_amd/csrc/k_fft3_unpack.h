@@ -42,7 +42,10 @@ __device__ __forceinline__ double fft3u_bdy_q(const QgBdyParams &B, int kl, cons
 // own_constr: part B of the constraint algebra (c1, c2, c3 from the zonal-mean column, k_cyclic.h) is evaluated by
 // every workgroup for itself and recorded by the first; 0: read from the scalars (y-slabs: k_constr_cyc ran before)
 // ---------------------------------------------------------------------------
-template <class PLAN, int NL, int NT>
+// AVG: the leapfrog averaging that follows the step (src/q-gcm.F:1345-1351) folded into the stores - the new po leaves as
+// 0.5*(po_new + U.pavg), the PV of the zonal boundary rows as 0.5*(q + U.qavg) (k_dst64_unpack<.., AVG> is the box twin);
+// whole-domain steps only, instantiated beside the plain kernel, which the other 24 steps of 25 run unchanged.
+template <class PLAN, int NL, int NT, bool AVG = false>
 __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const QgUnpackParams U, const QgBdyParams B,
                                                      const QgCycConstrParams Q, const int own_constr) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -136,12 +139,27 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
   }
   __syncthreads();
   QG_STAMP(2, 1);
+  // AVG: this step's po of the two rows, requested before the transform (in the store loop below the loads would sit
+  // between the write-through stores, one exposed round trip per round)
+  constexpr int NSTA = (NC / 2 + NT - 1) / NT;
+  double2 pva[AVG ? NSTA : 1], pvb[AVG ? NSTA : 1];
+  if (AVG) {
+    const double *va0 = U.pavg + fs * kl + (long)(ja - 1) * ldx;
+#pragma unroll
+    for (int it = 0; it < NSTA; ++it) {
+      const int t = tid + it * NT, tc = t < NC / 2 ? t : 0;
+      pva[it] = *reinterpret_cast<const double2 *>(va0 + 2 * tc);
+      pvb[it] = *reinterpret_cast<const double2 *>(va0 + (has_b ? ldx : 0) + 2 * tc);
+    }
+  }
   PLAN::template run<NT>(A, tw3, tid);
   QG_STAMP(2, 2);
 
   // ---- stores: the two pressure rows of layer kl, halo messages, zonal boundary rows + their PV -------------------
   const int jlo = D.g.jlo, jhi = D.g.jhi;
   double *pa = U.pnew + fs * kl + (long)(ja - 1) * ldx, *pb = pa + ldx;
+  auto avg_p = [&](long idx, double v) { return AVG ? 0.5 * (v + U.pavg[fs * kl + idx]) : v; };
+  auto avg_q = [&](long idx, double v) { return AVG ? 0.5 * (v + U.qavg[fs * kl + idx]) : v; };
   // this workgroup's rows next to a zonal boundary of the basin: it writes the boundary row of its layer as well
   const bool doS = rp == 0 && D.g.jr0 + D.g.joff == 2;
   const bool doN = rp == nrp - 1 && D.g.jr1 + D.g.joff == D.g.nyg - 1;
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
     const long o = (long)(jb - 1) * ldx + col;
     double q = fft3u_bdy_q<NL>(B, kl, south ? hS : hN, pin, south ? byS : byN);
     if (topo) q = q + B.ddynoc[o];
-    B.qo[fs * kl + o] = q;
+    B.qo[fs * kl + o] = avg_q(o, q);
   };
   // Every workgroup stores its two rows in the same plain loop (the kernel is bound by instruction issue).  The few with
   // more to do - halo messages, a zonal boundary row - come back for it in a second pass below.
@@ -193,8 +211,14 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
       const cplx z0 = A[STEP ? p0 + it * (2 * NT / PLAN::R1R2) : PLAN::pos_out(2 * t)];
       const cplx z1 = A[STEP ? p1 + it * (2 * NT / PLAN::R1R2) : PLAN::pos_out(2 * t + 1)];
       const double a0 = z0.x + ha, a1 = z1.x + ha, b0 = hb - z0.y, b1 = hb - z1.y;
-      qg_store16_wt(pa + 2 * t, a0, a1);
-      if (has_b) qg_store16_wt(pb + 2 * t, b0, b1);
+      if (AVG) {
+        const double2 ca = pva[AVG ? it : 0], cb = pvb[AVG ? it : 0];
+        qg_store16_wt(pa + 2 * t, 0.5 * (a0 + ca.x), 0.5 * (a1 + ca.y));
+        if (has_b) qg_store16_wt(pb + 2 * t, 0.5 * (b0 + cb.x), 0.5 * (b1 + cb.y));
+      } else {
+        qg_store16_wt(pa + 2 * t, a0, a1);
+        if (has_b) qg_store16_wt(pb + 2 * t, b0, b1);
+      }
       if (it == 0) {
         a00 = a0;
         b00 = b0;
@@ -246,34 +270,34 @@ __global__ __launch_bounds__(NT) void k_rfft3_unpack(const QgDstParams D, const 
           }
           if (doS) {
             const long o = (long)(jS - 1) * ldx + 2 * t;
-            *reinterpret_cast<double2 *>(U.pnew + fs * kl + o) = double2{hSk, hSk};
+            *reinterpret_cast<double2 *>(U.pnew + fs * kl + o) = double2{avg_p(o, hSk), avg_p(o + 1, hSk)};
             const double q0 = fft3u_bdy_q<NL>(B, kl, hS, a0, byS) + ddS[i].x, q1 = fft3u_bdy_q<NL>(B, kl, hS, a1, byS) + ddS[i].y;
-            *reinterpret_cast<double2 *>(B.qo + fs * kl + o) = double2{q0, q1};
+            *reinterpret_cast<double2 *>(B.qo + fs * kl + o) = double2{avg_q(o, q0), avg_q(o + 1, q1)};
           }
           if (doN) {
             const long o = (long)(jN - 1) * ldx + 2 * t;
-            *reinterpret_cast<double2 *>(U.pnew + fs * kl + o) = double2{hNk, hNk};
+            *reinterpret_cast<double2 *>(U.pnew + fs * kl + o) = double2{avg_p(o, hNk), avg_p(o + 1, hNk)};
             const double n0 = has_b ? b0 : a0, n1 = has_b ? b1 : a1;
             const double q0 = fft3u_bdy_q<NL>(B, kl, hN, n0, byN) + ddN[i].x, q1 = fft3u_bdy_q<NL>(B, kl, hN, n1, byN) + ddN[i].y;
-            *reinterpret_cast<double2 *>(B.qo + fs * kl + o) = double2{q0, q1};
+            *reinterpret_cast<double2 *>(B.qo + fs * kl + o) = double2{avg_q(o, q0), avg_q(o + 1, q1)};
           }
         }
       }
     }
   }
   if (tid == 0) { // column nxpo is column 1 (src/ocisubs.F:604)
-    pa[NC] = a00;
-    if (has_b) pb[NC] = b00;
+    pa[NC] = avg_p((long)(ja - 1) * ldx + NC, a00);
+    if (has_b) pb[NC] = avg_p((long)ja * ldx + NC, b00);
     if (U.msg_lo || U.msg_hi) {
       msg_p(ja, NC, a00); msg_q(ja, NC);
       if (has_b) { msg_p(ja + 1, NC, b00); msg_q(ja + 1, NC); }
     }
     if (doS) {
-      U.pnew[fs * kl + (long)(jS - 1) * ldx + NC] = hSk;
+      U.pnew[fs * kl + (long)(jS - 1) * ldx + NC] = avg_p((long)(jS - 1) * ldx + NC, hSk);
       bdy_col(true, NC, a00);
     }
     if (doN) {
-      U.pnew[fs * kl + (long)(jN - 1) * ldx + NC] = hNk;
+      U.pnew[fs * kl + (long)(jN - 1) * ldx + NC] = avg_p((long)(jN - 1) * ldx + NC, hNk);
       bdy_col(false, NC, has_b ? b00 : a00);
     }
   }

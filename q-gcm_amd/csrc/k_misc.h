@@ -355,9 +355,14 @@ __global__ __launch_bounds__(256) void k_lf_average(double *qo, const double *qo
 }
 
 // the scalar part alone: the fields were averaged by the step's own kernels (QgTendParams.avg, QgUnpackParams.pavg)
-__global__ void k_lf_average_scalars(QgScalars *sc, int nl) {
-  if (threadIdx.x == 0)
-    for (int k = 0; k < nl - 1; ++k) sc->dpioc[k] = 0.5 * (sc->dpioc[k] + sc->dpiocp[k]);
+__global__ void k_lf_average_scalars(QgScalars *sc, int nl, int cyc) {
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < nl - 1; ++k) sc->dpioc[k] = 0.5 * (sc->dpioc[k] + sc->dpiocp[k]);
+  if (cyc)
+    for (int k = 0; k < nl; ++k) {
+      sc->ocncs[k] = 0.5 * (sc->ocncs[k] + sc->ocncsp[k]);
+      sc->ocncn[k] = 0.5 * (sc->ocncn[k] + sc->ocncnp[k]);
+    }
 }
 
 // ---------------------------------------------------------------------------

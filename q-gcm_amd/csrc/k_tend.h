@@ -328,6 +328,7 @@ __global__ __launch_bounds__(TEND_NT, (WTQ && NL <= 4) ? TEND_WAVES_WTQ : TEND_W
   // ---- epilogue operands of this thread's own points: requested while the LAST layer is computed (the
   // registers of the layer prefetch are free by then); the old qo of the wall rows is read in the epilogue
   double e_qm[NL][RPT], e_wek[RPT], e_ent[RPT], e_ddy[RPT];
+  double e_qo[AVG ? NL : 1][RPT]; // AVG: this step's qo of the thread's own points
 
   double dq[NL][RPT];
   double d2bot[RPT];
@@ -374,6 +375,10 @@ __global__ __launch_bounds__(TEND_NT, (WTQ && NL <= 4) ? TEND_WAVES_WTQ : TEND_W
         e_ddy[r] = P.ddynoc[o];
 #pragma unroll
         for (int kk = 0; kk < NL; ++kk) e_qm[kk][r] = P.qnew[fs * kk + o];
+        if (AVG) {
+#pragma unroll
+          for (int kk = 0; kk < NL; ++kk) e_qo[kk][r] = P.qo[fs * kk + o];
+        }
       }
     }
     // ---- Del^2(pom) on the halo-2 region (qgosubs.F:94-127) ----------
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(TEND_NT, (WTQ && NL <= 4) ? TEND_WAVES_WTQ : TEND_W
       for (int k = 0; k < NL; ++k) {
         dqp[k] = dq[k][r];
         qmp[k] = e_qm[k][r];
-        qop[k] = (wallrow || AVG) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+        qop[k] = AVG ? e_qo[AVG ? k : 0][r] : (wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0);
       }
       tend_point<NL, CYC, true, AVG>(P, gi0, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r], valid);
     }
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(TEND_NT, (WTQ && NL <= 4) ? TEND_WAVES_WTQ : TEND_W
       for (int k = 0; k < NL; ++k) {
         dqp[k] = dq[k][r];
         qmp[k] = e_qm[k][r];
-        qop[k] = (wallrow || AVG) ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0;
+        qop[k] = AVG ? e_qo[AVG ? k : 0][r] : (wallrow ? P.qo[fs * k + (long)(gj - 1) * ldx + (gi - 1)] : 0.0);
       }
       tend_point<NL, CYC, false, AVG>(P, gi, gj, dqp, d2bot[r], qmp, qop, e_wek[r], e_ent[r], e_ddy[r]);
     }

@@ -934,7 +934,7 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   // 256 MiB Infinity Cache (NAtl 5 km: 150 MB: -1 us per step; SOcn 5 km's 425 MB: +8 us); plain stores and 32-wide
   // tiles at the HBM-bound sizes (k_tend.h)
   const bool wtq = tend_wtq(c);
-  if (c->avg_now && (!wtq || g.cyc || g.nl > 4 || part != TEND_ALL)) QG_FAIL("k_tend: the fused leapfrog averaging belongs to whole-domain box steps");
+  if (c->avg_now && (part != TEND_ALL || (g.cyc ? g.nl != 3 : (!wtq || g.nl > 4)))) QG_FAIL("k_tend: the fused leapfrog averaging belongs to whole-domain steps of the fused inverse-row kernels");
   const TendTiling T = g.cyc ? (wtq ? tend_tiling<true, TEND_TX>(g) : tend_tiling<true, TEND_TX_WIDE>(g))
                              : (wtq ? tend_tiling<false, TEND_TX>(g) : tend_tiling<false, TEND_TX_WIDE>(g));
   if (part != TEND_ALL && T.gy < 3) QG_FAIL("k_tend: a slab of fewer than three tile rows cannot be split");
@@ -961,7 +961,10 @@ static int launch_tend(qgcm_hip_ctx *c, bool upd_dpi = false, bool oml_final = f
   else if (g.cyc) hipLaunchKernelGGL((k_tend<NLV, true, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);     \
   else if (wtq) hipLaunchKernelGGL((k_tend<NLV, false, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);       \
   else hipLaunchKernelGGL((k_tend<NLV, false, false>), grid, dim3(TEND_NT), 0, c->stream, P, S, F)
-  if (c->avg_now) { // the step before a leapfrog averaging stores the averaged qo itself (one_step)
+  if (c->avg_now && g.cyc) { // (long-row cyclic oceans: k_rfft3_unpack<.., AVG> does the rest)
+    if (wtq) hipLaunchKernelGGL((k_tend<3, true, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);
+    else hipLaunchKernelGGL((k_tend<3, true, false, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F);
+  } else if (c->avg_now) { // the step before a leapfrog averaging stores the averaged qo itself (one_step)
     switch (g.nl) {
       case 2: hipLaunchKernelGGL((k_tend<2, false, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F); break;
       case 3: hipLaunchKernelGGL((k_tend<3, false, true, true>), grid, dim3(TEND_NT), 0, c->stream, P, S, F); break;
@@ -1369,6 +1372,11 @@ static int launch_fft3_unpack(qgcm_hip_ctx *c, bool own_constr, double *msg_lo =
   P.msg_lo = msg_lo;
   P.msg_hi = msg_hi;
   for (int i = 0; i < g.nl * g.nl; ++i) P.ctm2l[i] = c->prm.ctm2loc[i];
+  if (c->avg_now) {
+    if (msg_lo || msg_hi || !own_constr) QG_FAIL("k_rfft3_unpack: the fused leapfrog averaging belongs to whole-domain steps");
+    P.pavg = c->p[c->ip];     // this step's po (the launch writes the old pom buffer)
+    P.qavg = c->q[c->iq ^ 1]; // this step's qo (iq already points at the new qo)
+  }
   QgBdyParams B;
   fill_bdy_params(c, B);
   const int npairs = (g.jr1 - g.jr0 + 2) / 2;
@@ -1380,7 +1388,8 @@ static int launch_fft3_unpack(qgcm_hip_ctx *c, bool own_constr, double *msg_lo =
 #define QG_FFT3U_LAUNCH(ID, R1, R2, R3)                                                                                   \
     if (c->fft3 == ID) {                                                                                                  \
       typedef Fft3Plan<R1, R2, R3> PL;                                                                                    \
-      hipLaunchKernelGGL((k_rfft3_unpack<PL, 3, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, c->stream, D, P, B, Q, own_constr ? 1 : 0); \
+      if (c->avg_now) hipLaunchKernelGGL((k_rfft3_unpack<PL, 3, FFT3_NT, true>), grid, dim3(FFT3_NT), c->fft3_lds, c->stream, D, P, B, Q, 1); \
+      else hipLaunchKernelGGL((k_rfft3_unpack<PL, 3, FFT3_NT>), grid, dim3(FFT3_NT), c->fft3_lds, c->stream, D, P, B, Q, own_constr ? 1 : 0); \
     }
     QG_FFT3_PLANS(QG_FFT3U_LAUNCH)
 #undef QG_FFT3U_LAUNCH
@@ -1997,7 +2006,9 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   // the boundary qo (one extra read of this step's po) - instead of a pass of its own over six fields (133 MB at 5 km,
   // 21 us every 25 steps); the integrals dpioc follow in a one-thread launch.  Same expressions: bitwise the same fields.
   const bool avg = (s - 1) % c->avg_period == 0;
-  c->avg_now = avg && fused_constr && c->g.nl <= 4 && tend_wtq(c) && !c->oml.on && !c->no_fused_avg;
+  const bool avg_box = fused_constr && c->g.nl <= 4 && tend_wtq(c);
+  const bool avg_cyc = c->g.cyc && can_fuse_fft3_unpack(c) && !c->no_fused_constr; // (ocinvq_impl: launch_fft3_unpack(c, true))
+  c->avg_now = avg && (avg_box || avg_cyc) && !c->oml.on && !c->no_fused_avg;
   const bool avg_fused = c->avg_now;
   int rc = launch_tend(c, fused_constr, c->oml.on);
   if (!rc) {
@@ -2008,7 +2019,7 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   if (rc) return 1;
   if (avg_fused) {
     KTimer t(c, KN_LFAVG);
-    hipLaunchKernelGGL(k_lf_average_scalars, dim3(1), dim3(64), 0, c->stream, c->sc, c->g.nl);
+    hipLaunchKernelGGL(k_lf_average_scalars, dim3(1), dim3(64), 0, c->stream, c->sc, c->g.nl, c->g.cyc ? 1 : 0);
     HIPCHECK(hipGetLastError());
   } else if (avg) {
     if (qgcm_hip_lf_average(c)) return 1; // incl. sst when the mixed layer is on

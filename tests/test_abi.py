@@ -77,7 +77,7 @@ def test_hot_kernels_do_not_spill(repo_root):
     hot = ["_Z6k_tendILi3ELb0ELb", "_Z6k_tendILi3ELb1ELb", "_Z7k_dst64ILi15ELb0EEv", "_Z8k_thomasILi16ELi0ELb0E",
            "_Z8k_thomasILi10ELi0ELb1E", "_Z8k_thomasILi2ELi0ELb1E", "_Z8k_thomasILi20ELi", "_Z8k_thomasILi32ELi", "_Z14k_dst64_unpackILi15ELi3ELb1ELb0ELb1ELb",
            "_Z8k_rfft64ILi6ELb0EEv", "_Z15k_rfft64_unpackILi6ELi3ELb1ELb1EEv", "_Z10k_rfft_cycILb0E8Fft3PlanILi16ELi16ELi18EELi256EEv",
-           "_Z10k_rfft_cycILb1E8Fft3PlanILi16ELi16ELi18EELi256EEv", "_Z14k_rfft3_unpackI8Fft3PlanILi16ELi16ELi18EELi3ELi256EEv", "_Z9k_dst_boxILb0ELi256E8Fft3PlanILi12ELi20ELi20EEEv", "_Z13k_thomas_corr", "_Z8k_thomasILi10ELi1ELb0E",
+           "_Z10k_rfft_cycILb1E8Fft3PlanILi16ELi16ELi18EELi256EEv", "_Z14k_rfft3_unpackI8Fft3PlanILi16ELi16ELi18EELi3ELi256ELb", "_Z9k_dst_boxILb0ELi256E8Fft3PlanILi12ELi20ELi20EEEv", "_Z13k_thomas_corr", "_Z8k_thomasILi10ELi1ELb0E",
            "_Z10k_oml_step11QgOmlParams", "_Z11k_oml_entoc11QgOmlParams"]
     for h in hot:
         hits = [k for k in res if k.startswith(h)]

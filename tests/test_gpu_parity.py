@@ -1436,3 +1436,34 @@ def test_fused_leapfrog_average_is_bitwise(nlo, monkeypatch):
         for f, x, y in zip(FIELDS, sa, sb):
             assert np.array_equal(x, y), f
         assert np.array_equal(np.asarray(ca), np.asarray(cb))
+
+
+@pytest.mark.gpu
+def test_fused_leapfrog_average_long_cyclic_rows_is_bitwise(monkeypatch):
+    """The same for the long rows of a cyclic ocean (k_tend<3, true, .., AVG> + k_rfft3_unpack<.., AVG>: new po, the PV of
+    the zonal boundary rows, and the integrals dpioc / ocncs / ocncn in the one-thread launch): bit for bit the fields and
+    scalars of the run that keeps k_lf_average (QGCM_HIP_NO_FUSED_AVG=1), eager and graph replay, 1 + 25 + 34 steps."""
+    from qgcm_hip import OceanModel, synth
+    cfg = preset("cyc_2880")
+    po = synth.gaussian_eddy(cfg, noise=1e-2)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("QGCM_HIP_NO_FUSED_AVG", flag)
+        m = OceanModel(cfg)
+        try:
+            m.set_p(po, 0.99 * po)
+            m.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+            m.set_cyc_forcing(*synth.tau_line_integrals(cfg, tx))
+            snaps = []
+            for n, s0 in ((1, 1), (25, 2), (34, 27)):
+                m.steps(n, s0=s0)
+                snaps.append((m.get_state(), np.asarray(m.get_scalars())))
+            out[flag] = snaps
+        finally:
+            m.close()
+    for (sa, ca), (sb, cb) in zip(out["1"], out["0"]):
+        for f, x, y in zip(FIELDS, sa, sb):
+            assert np.array_equal(x, y), f
+        assert np.array_equal(ca, cb)
