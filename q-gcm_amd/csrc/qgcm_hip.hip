@@ -2008,7 +2008,7 @@ static int one_step(qgcm_hip_ctx *c, int s) {
   const bool avg = (s - 1) % c->avg_period == 0;
   const bool avg_box = fused_constr && c->g.nl <= 4 && tend_wtq(c);
   const bool avg_cyc = c->g.cyc && can_fuse_fft3_unpack(c) && !c->no_fused_constr; // (ocinvq_impl: launch_fft3_unpack(c, true))
-  c->avg_now = avg && (avg_box || avg_cyc) && !c->oml.on && !c->no_fused_avg;
+  c->avg_now = avg && (avg_box || avg_cyc) && !c->no_fused_avg;
   const bool avg_fused = c->avg_now;
   int rc = launch_tend(c, fused_constr, c->oml.on);
   if (!rc) {
@@ -2021,6 +2021,7 @@ static int one_step(qgcm_hip_ctx *c, int s) {
     KTimer t(c, KN_LFAVG);
     hipLaunchKernelGGL(k_lf_average_scalars, dim3(1), dim3(64), 0, c->stream, c->sc, c->g.nl, c->g.cyc ? 1 : 0);
     HIPCHECK(hipGetLastError());
+    if (c->oml.on && launch_oml_average(c)) return 1; // the mixed-layer temperature keeps its own (one-field) pass
   } else if (avg) {
     if (qgcm_hip_lf_average(c)) return 1; // incl. sst when the mixed layer is on
   }

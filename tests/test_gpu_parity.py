@@ -1467,3 +1467,42 @@ def test_fused_leapfrog_average_long_cyclic_rows_is_bitwise(monkeypatch):
         for f, x, y in zip(FIELDS, sa, sb):
             assert np.array_equal(x, y), f
         assert np.array_equal(ca, cb)
+
+
+@pytest.mark.gpu
+def test_fused_leapfrog_average_with_mixed_layer_is_bitwise(monkeypatch):
+    """... and with the ocean mixed layer on the device: po / qo are averaged by the step's kernels, sst keeps its own
+    one-field pass (k_oml_average), the mixed layer's final reduction rides in k_tend<.., AVG> as in the plain kernel."""
+    from qgcm_hip import OceanModel, oml_preset, synth
+    from qgcm_hip.config import OceanConfig
+    cfg = OceanConfig("nl3_box_avg_oml", 16, 10, 12, 6, 16, 3, dxo=2.5e4, dta=240.0, fnot=9.37456e-05, beta=1.7536e-11,
+                      cyclic=False, hoc=(350.0, 750.0, 2900.0), gpoc=(0.025, 0.0125), ah2oc=(0.0,) * 3, ah4oc=(1.2e10,) * 3)
+    om = oml_preset(cfg)
+    sst, sstm, fnet, txo, tyo = synth.mixed_layer_fields(cfg, om)
+    wekto, _ = synth.wekpo_from_tau(cfg, txo, tyo)
+    po = synth.gaussian_eddy(cfg, noise=2e-2, seed=5)
+    tx, ty = synth.wind_stress(cfg)
+    _, wek = synth.wekpo_from_tau(cfg, tx, ty)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("QGCM_HIP_NO_FUSED_AVG", flag)
+        m = OceanModel(cfg)
+        try:
+            m.oml_init(om)
+            m.oml_set_state(sst, sstm)
+            m.oml_set_forcing(fnet, wekto, txo, tyo)
+            m.set_p(po, np.asfortranarray(0.99 * po))
+            m.set_forcing(wek, np.zeros_like(wek), np.zeros(cfg.nlo - 1))
+            snaps = []
+            for n, s0 in ((1, 1), (25, 2), (34, 27)):
+                m.steps(n, s0=s0)
+                snaps.append((m.get_state(), np.asarray(m.get_scalars()), m.oml_get_state()))
+            out[flag] = snaps
+        finally:
+            m.close()
+    for (sa, ca, ta), (sb, cb, tb) in zip(out["1"], out["0"]):
+        for f, x, y in zip(FIELDS, sa, sb):
+            assert np.array_equal(x, y), f
+        assert np.array_equal(ca, cb)
+        for x, y in zip(ta, tb):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
