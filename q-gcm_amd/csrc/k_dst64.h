@@ -645,6 +645,20 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
 #pragma unroll
       for (int m = 1; m < NL; ++m) oc[r][it][m - 1] = ok ? *reinterpret_cast<const double2 *>(U.ochom + fs * (m - 1) + o) : double2{0.0, 0.0};
     }
+  // AVG: this step's po of the same column pairs, requested here as well (in the store loop the loads sat between the
+  // write-through stores: one exposed round trip per round, +12 us on the averaging step's launch)
+  double2 pcv[AVG ? 2 : 1][AVG ? NIT : 1][AVG ? NL : 1];
+  if (AVG) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int q = tid + it * NT, qc = q < NPAIR ? q : 0;
+        const long o = (long)(ja + ((r == 0 || has_b) ? r : 0) - 1) * U.g.ldx + (3 + 2 * qc - 1);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) pcv[AVG ? r : 0][AVG ? it : 0][AVG ? k : 0] = *reinterpret_cast<const double2 *>(U.pavg + fs * k + o);
+      }
+  }
   const bool wallcol = !CONSTR && (lane == 0 && wv < 2);
   WallPre wpre;
   if (!CONSTR) wall_prefetch(wallcol, wv, wpre);
@@ -688,7 +702,7 @@ __global__ __launch_bounds__(64 * (NL + (CONSTR ? 1 : 0))) void k_dst64_unpack(c
       if (AVG) {
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-          const double2 pc = *reinterpret_cast<const double2 *>(U.pavg + fs * k + o);
+          const double2 pc = pcv[AVG ? r : 0][AVG ? it : 0][AVG ? k : 0];
           qg_store16_wt(U.pnew + fs * k + o, 0.5 * (pla[k] + pc.x), 0.5 * (plb[k] + pc.y));
         }
       } else {
